@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- utterances/sec of one GE2E training step on the HIP path (BASELINE.json's metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one full Trainer.Train_Step of the reference (Train.py:140-168) on one synthetic batch per
+rank: forward -> GE2E loss -> backward (bucketed RCCL gradient mean overlapped with it when N > 1)
+-> clip_grad_norm_(1.0) -> AdamW.  Workload = BASELINE.json configs[1]: 64 speakers x 15 utterances x
+160 frames x 80 mel per rank (weak scaling; the reference's DistributedSampler semantics), dropout 0.1
+on, bf16 storage / fp32 accumulate.  Inputs are generated on the device before the timed region.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     live hipEvent timing of the dominant kernel class (projection GEMMs) inside the timed region
+  "cpu_baseline": the CPU oracle (numpy port of the reference's Device '-1' path) timed on this box's host
+                  cores on a bounded sample of the same workload (N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from speaker_embedding_torch_amd import _lib  # noqa: E402
+from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters  # noqa: E402
+from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
+                    "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD}
+
+
+def synth_mel(n, mel, t, seed, device):
+    """x = clamp(-5 + 2 z, log(1e-5), 2): the log-mel range of meldataset.py:51-52,93-94."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    return (torch.randn(n, mel, t, device=device, generator=g) * 2.0 - 5.0).clamp_(-11.5129, 2.0)
+
+
+def cpu_baseline(speakers, utts, frames, mel, budget_speakers=4, steps=2):
+    """Times the oracle's Train_Step (fwd + loss + bwd + clip + AdamW, dropout on) on the host cores."""
+    import numpy as np
+    from oracle import ge2e_oracle as O      # checker / baseline only -- never on the product path
+    sp = min(speakers, budget_speakers)
+    params = O.formula_params()
+    x = O.formula_mel(7, sp * utts, mel, frames, logmel=True)
+    state = {}
+    O.train_step(params, x[: utts * 2], utts, state)          # warm-up (BLAS threads, page-in)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        O.train_step(params, x, utts, state, seed=1234, step=s)
+    dt = (time.perf_counter() - t0) / steps
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    return {"value": round(sp * utts / dt, 2), "unit": "utterances/sec", "cores": int(cores), "kind": "port",
+            "sample": f"{steps} Train_Steps of {sp} spk x {utts} utt x {frames} fr x {mel} mel "
+                      f"({sp * utts} of the {speakers * utts} utterances of one step), numpy fp32 oracle, dropout on"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--speakers", type=int, default=None)
+    ap.add_argument("--utts", type=int, default=None)
+    ap.add_argument("--frames", type=int, default=160)
+    ap.add_argument("--roofline-kernel", default="gemm", choices=sorted(ROOFLINE_CLASSES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("-hp", "--hyper_parameters", default=os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the GE2E hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        from speaker_embedding_torch_amd.distributed import apply_gradient_allreduce
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", rank=rank, world_size=world)
+
+    hp = Load_Hyper_Parameters(args.hyper_parameters)
+    S = args.speakers or hp.Train.Batch.Train.Speaker
+    P = args.utts or hp.Train.Batch.Train.Pattern_per_Speaker
+    T, mel = args.frames, hp.Sound.Mel_Dim
+
+    torch.manual_seed(0)                       # same initial weights on every rank (then broadcast anyway)
+    model = GE2E(hp, precision=args.precision, seed=1234 + rank).to(dev)
+    criterion = GE2E_Loss().to(dev)
+    if world > 1:
+        model = apply_gradient_allreduce(model)
+    optimizer = torch.optim.AdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,
+                                  betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2), eps=hp.Train.ADAM.Epsilon)
+    model.train()
+    batches = [synth_mel(S * P, mel, T, 1234 + rank + 1000 * i, dev) for i in range(2)]   # resident in HBM
+
+    def train_step(i):
+        """Trainer.Train_Step (Train.py:140-168) without the logging-only loss.item() host sync."""
+        emb = model(batches[i & 1])
+        loss = criterion(emb, P)
+        optimizer.zero_grad()
+        loss.backward()
+        if hp.Train.Gradient_Norm > 0.0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.Train.Gradient_Norm)
+        optimizer.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        train_step(i)
+    hnd = model._handle()
+    klass = ROOFLINE_CLASSES[args.roofline_kernel]
+    if not args.no_roofline:
+        hnd.profile_enable(klass)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = train_step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    hnd.profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = tt.item()
+    final_loss = loss.item()
+    if not (final_loss == final_loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    roofline = None
+    if not args.no_roofline:
+        ms, work, launches = hnd.profile_read(klass)
+        if launches and ms > 0:
+            achieved = work / (ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": {"gemm": "gemm_nt_kernel<128x128>", "gemm_ln": "gemm_nt_kernel<128x256,LN>",
+                        "wgrad": "wgrad_kernel", "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
+                        "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
+                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                        "class_ms_per_step": round(ms / args.steps, 3)}
+    if rank == 0:
+        out = {
+            "metric": "utterances/sec (64spk x 15utt, T=160, 80-mel) training step",
+            "value": round(S * P * world * args.steps / dt, 1), "unit": "utterances/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{S} spk x {P} utt x {T} fr x {mel} mel per GPU, full Train_Step "
+                                   f"(fwd+GE2E loss+bwd+clip+AdamW), dropout 0.1, random-init weights",
+                       "per_gpu_batch": S * P, "global_batch": S * P * world,
+                       "parallelism": f"dp{world}" if world > 1 else "single"},
+            "final_loss": round(final_loss, 5),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S, P, T, mel)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,136 @@
+/* ge2e_hip.h -- C ABI of libge2e_hip.so: the MI355X (gfx950) GE2E speaker-embedding hot path.
+ *
+ * The reference (CODEJIN/Speaker_Embedding_Torch) has no FFI; its seam for this path is the Python
+ * nn.Module API.  Each entry point below names the reference code it replaces:
+ *
+ *   ge2e_encoder_forward   <-  Modules.py:46-59   GE2E.forward            (callers Train.py:146,204,239; Inference.py:159)
+ *   ge2e_encoder_backward  <-  autograd of the above at Train.py:153      (loss.backward())
+ *   ge2e_loss_forward      <-  Modules.py:121-156 GE2E_Loss.forward       (callers Train.py:147-150,205-208)
+ *   ge2e_loss_backward     <-  autograd of the above at Train.py:153
+ *   ge2e_param_*           <-  the state_dict key set loaded strictly at Train.py:285 / Inference.py:212
+ *
+ * Conventions: plain pointers and sizes only; all device buffers are allocated and owned by the caller
+ * (PyTorch); every call is asynchronous on the hipStream_t it is handed and never synchronises the device;
+ * the library holds no thread-local state (backward is invoked from the autograd thread).
+ * Every function returns 0 on success, a negative GE2E_E* code for invalid arguments, or a positive
+ * hipError_t passed through; ge2e_last_error() gives the text.  No C++ exception crosses this boundary.
+ */
+#ifndef GE2E_HIP_H
+#define GE2E_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GE2E_ABI_VERSION 1
+
+enum {
+    GE2E_OK = 0,
+    GE2E_EINVAL = -1,        /* bad argument / null pointer */
+    GE2E_EUNSUPPORTED = -2,  /* shape outside what the kernels were built for */
+    GE2E_EWORKSPACE = -3     /* workspace too small */
+};
+
+enum { GE2E_PREC_F32 = 0, GE2E_PREC_BF16 = 1 };
+
+/* Mirrors the `Sound.Mel_Dim` / `GE2E.*` block of Hyper_Parameters.yaml:1-18 plus the arithmetic mode. */
+typedef struct ge2e_config {
+    int32_t mel_dim;         /* Sound.Mel_Dim (80)                                   */
+    int32_t emb;             /* GE2E.Embedding_Size (256; the kernels require 256)   */
+    int32_t heads;           /* GE2E.Transformer.Head (emb / heads must be 64)       */
+    int32_t layers;          /* GE2E.Transformer.Num_Layers                          */
+    int32_t ffn;             /* dim_feedforward = 4 * emb (Modules.py:28)            */
+    int32_t max_position;    /* GE2E.Positional_Encoding.Max_Position                */
+    float pe_dropout;        /* GE2E.Positional_Encoding.Dropout_Rate                */
+    float tf_dropout;        /* GE2E.Transformer.Dropout_Rate                        */
+    float ln_eps;            /* torch LayerNorm default 1e-5                         */
+    int32_t precision;       /* GE2E_PREC_F32: fp32 MFMA (parity path); GE2E_PREC_BF16: bf16 storage, fp32 accumulate */
+} ge2e_config;
+
+typedef struct ge2e_handle_s* ge2e_handle;
+
+int ge2e_abi_version(void);
+int ge2e_create(const ge2e_config* cfg, ge2e_handle* out);     /* no GPU call is made here */
+int ge2e_destroy(ge2e_handle h);
+const char* ge2e_last_error(ge2e_handle h);
+
+/* Parameter table == reference GE2E.parameters() order (43 tensors, 2,456,321 floats for the default config). */
+int ge2e_param_count(ge2e_handle h);
+const char* ge2e_param_name(ge2e_handle h, int index);                 /* state_dict key */
+int64_t ge2e_param_numel(ge2e_handle h, int index);
+int64_t ge2e_param_offset(ge2e_handle h, int index);                   /* element offset in the flat gradient buffer */
+int64_t ge2e_param_total(ge2e_handle h);
+
+/* Bytes of caller-owned scratch for n_utts x frames.  train != 0 keeps the activations backward needs. */
+size_t ge2e_workspace_bytes(ge2e_handle h, int n_utts, int frames, int train);
+/* Longest frames count the attention kernels were instantiated for. */
+int ge2e_max_frames(ge2e_handle h);
+
+/* mel:    device fp32 [n_utts, mel_dim, frames]  (channels-first, as Datasets.Collater produces, Datasets.py:84)
+ * params: HOST array of ge2e_param_count() DEVICE pointers (fp32), table order
+ * pe:     device fp32 [emb, max_position]  -- the `positional_encoding.pe` buffer of the state_dict
+ * out_emb:device fp32 [n_utts / samples, emb]  unit-norm d-vectors
+ * train:  0 = eval (no dropout, nothing kept); 1 = train (dropout from (seed, step), activations kept in workspace) */
+int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                         const float* const* params, const float* pe, float* out_emb,
+                         void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step);
+
+/* Must follow a train-mode forward on the SAME workspace, inputs, seed and step.
+ * d_emb:      device fp32 [n_utts / samples, emb]
+ * grads_flat: device fp32 [ge2e_param_total()], OVERWRITTEN with dL/dparam at ge2e_param_offset(i) */
+int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                          const float* const* params, const float* d_emb, float* grads_flat,
+                          void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step);
+
+/* Same, reporting gradient buckets as soon as their last kernel has been ENQUEUED on `stream` (replaces the
+ * post-backward queue_callback of reference distributed.py:114-118): cb(user, element_offset, element_count)
+ * is called on the calling host thread, in this order: [final norm + projection], [layer L-1], ..., [layer 0],
+ * [prenet + alpha].  The caller records an event and starts that bucket's all-reduce on its comm stream. */
+typedef void (*ge2e_bucket_cb)(void* user, int64_t element_offset, int64_t element_count);
+int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                             const float* const* params, const float* d_emb, float* grads_flat,
+                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
+                             ge2e_bucket_cb cb, void* user);
+
+/* GE2E loss over speakers x utts embeddings (row i belongs to speaker i / utts).
+ * loss_ws: device scratch of ge2e_loss_workspace_bytes(); kept between forward and backward. */
+size_t ge2e_loss_workspace_bytes(int speakers, int utts, int emb);
+int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
+                      float w, float b, float* loss, void* loss_ws, size_t loss_ws_bytes);
+/* d_loss: device fp32 scalar (upstream gradient); d_emb: device fp32 [speakers*utts, emb] */
+int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
+                       float w, float b, const float* d_loss, float* d_emb, void* loss_ws, size_t loss_ws_bytes);
+
+/* Live per-kernel timing for the roofline leg of bench.py.  While a class bit is enabled every launch of that
+ * kernel class is bracketed by hipEvents ON THE LAUNCH STREAM; ge2e_profile_read() synchronises those events,
+ * returns the summed duration, the summed algorithmic work (FLOPs for the MFMA classes, bytes for the others)
+ * and the launch count, and resets the class.  Disabled (mask 0) there is no overhead. */
+enum {
+    GE2E_K_GEMM = 1,       /* 128x128-tile projection GEMMs (prenet, in_proj, FFN1, dgrads)   work = 2*M*N*K   */
+    GE2E_K_GEMM_LN = 2,    /* 128x256-tile GEMMs with the residual+LayerNorm epilogue         work = 2*M*N*K   */
+    GE2E_K_WGRAD = 4,      /* weight-gradient GEMMs                                            work = 2*R*N*K   */
+    GE2E_K_ATTN_FWD = 8,   /* fused attention forward                                          work = 4*T*T*64 per head */
+    GE2E_K_ATTN_BWD = 16,  /* fused attention backward                                         work = 14*T*T*64 per head */
+    GE2E_K_LN_BWD = 32     /* LayerNorm backward                                               work = bytes moved */
+};
+int ge2e_profile_enable(ge2e_handle h, int class_mask);
+int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, int64_t* launches);
+
+/* Diagnostics: byte offset/size inside the workspace of a named intermediate of the last forward
+ * ("h0", "qkv.<l>", "o.<l>", "h1.<l>", "f.<l>", "h2.<l>", and after a backward the scratch of the LAST
+ * processed layer: "dF", "dHb", "dP", "dM", "dO", "dQKV", "dHa"; element type follows cfg.precision).
+ * Used by the parity tests to localise a failing kernel; returns GE2E_EINVAL for unknown names. */
+int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int train,
+                   size_t* offset_bytes, size_t* size_bytes);
+
+/* Host-side helpers shared with the CPU oracle (dropout stream definition; no GPU needed). */
+uint32_t ge2e_drop_key(uint64_t seed, uint64_t step, int site);
+int ge2e_drop_keep(uint32_t key, uint32_t index, float p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GE2E_HIP_H */

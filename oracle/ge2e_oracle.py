@@ -215,7 +215,7 @@ def _ln_bwd(dy, xhat, rstd, w):
 # --------------------------------------------------------------------------------------
 
 def encoder_forward(params, x, samples=1, heads=4, train=False, seed=0, step=0,
-                    p_pe=0.1, p_tf=0.1, eps=1e-5, max_position=1024, taps=None):
+                    p_pe=0.1, p_tf=0.1, eps=1e-5, max_position=1024, taps=None, pe=None):
     """GE2E.forward (Modules.py:46-59).  x: [N, Mel, T].  Returns (emb [N/samples, D], cache)."""
     dt = x.dtype
     n, mel, t = x.shape
@@ -229,7 +229,9 @@ def encoder_forward(params, x, samples=1, heads=4, train=False, seed=0, step=0,
     # prenet 1x1 conv + ReLU (Modules.py:50-51)
     z0 = np.einsum("nmt,dm->ntd", x, wp) + params["prenet.bias"]
     a0 = np.maximum(z0, 0)
-    pe = sinusoid_pe(max_position, d, dt)[:t]                      # Modules.py:98-109
+    # pe: the `positional_encoding.pe` buffer is checkpoint DATA (state_dict key); callers may pass it as
+    # [max_position, d] so that oracle and device read the same table.  Default: rebuild it (Modules.py:84-90).
+    pe = (sinusoid_pe(max_position, d, dt) if pe is None else np.asarray(pe, dt))[:t]   # Modules.py:98-109
     alpha = params["positional_encoding.alpha"][0]
     h = a0 + alpha * pe[None]
     h, keep_pe = _dropout(h, drop_key(seed, step, SITE_PE), p_pe, train)
@@ -265,6 +267,7 @@ def encoder_forward(params, x, samples=1, heads=4, train=False, seed=0, step=0,
         h = h2
         if taps is not None:
             taps[f"layer{l}"] = h
+            taps[f"qkv{l}"], taps[f"o{l}"], taps[f"h1_{l}"], taps[f"f{l}"] = qkv, o, h1, f
     # final LN applies to every row in torch, but only t = 0 is consumed (Modules.py:54)
     zf, xhatf, rstdf = _ln_fwd(h[:, 0, :], params["transformer.norm.weight"], params["transformer.norm.bias"], eps)
     if taps is not None:
@@ -278,7 +281,7 @@ def encoder_forward(params, x, samples=1, heads=4, train=False, seed=0, step=0,
     return emb, c
 
 
-def encoder_backward(params, c, d_emb):
+def encoder_backward(params, c, d_emb, taps=None):
     """Gradient of every parameter given d(loss)/d(emb); what autograd computes at Train.py:153."""
     dt = d_emb.dtype
     n, t, d, heads, samples = c["n"], c["t"], c["d"], c["heads"], c["samples"]
@@ -332,9 +335,15 @@ def encoder_backward(params, c, d_emb):
         g[p + "self_attn.in_proj_weight"] = np.einsum("ntf,ntd->fd", dqkv, lc["h_in"])
         g[p + "self_attn.in_proj_bias"] = dqkv.sum((0, 1))
         dhh = dpre1 + dqkv @ params[p + "self_attn.in_proj_weight"]
+        if taps is not None:
+            taps[f"dF{l}"], taps[f"dHb{l}"], taps[f"dP{l}"], taps[f"dM{l}"] = df, dh1, dpre1, da
+            taps[f"dO{l}"] = do.transpose(0, 2, 1, 3).reshape(n, t, d)
+            taps[f"dQKV{l}"] = dqkv
     dhp = undrop(dhh, c["keep_pe"], p_pe)
     g["positional_encoding.alpha"] = np.array([(dhp * c["pe"][None]).sum()], dt)
     dz0 = dhp * (c["z0"] > 0)
+    if taps is not None:
+        taps["dHa"] = dz0
     g["prenet.weight"] = np.einsum("ntd,nmt->dm", dz0, c["x"])[:, :, None]
     g["prenet.bias"] = dz0.sum((0, 1))
     return OrderedDict((name, g[name]) for name, _ in param_specs(c["x"].shape[1], d, c["layers"], params["transformer.layers.0.linear1.weight"].shape[0]))

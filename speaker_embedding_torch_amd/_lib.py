@@ -1,0 +1,164 @@
+"""ctypes binding of libge2e_hip.so (include/ge2e_hip.h).  There is no fallback: if the library is
+missing, or a call fails, a RuntimeError is raised."""
+import ctypes as C
+import os
+import threading
+
+from ._build import LIB
+
+_lock = threading.Lock()
+_lib = None
+
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
+
+PREC_F32, PREC_BF16 = 0, 1
+K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD = 1, 2, 4, 8, 16, 32
+
+
+class Config(C.Structure):
+    _fields_ = [("mel_dim", C.c_int32), ("emb", C.c_int32), ("heads", C.c_int32), ("layers", C.c_int32),
+                ("ffn", C.c_int32), ("max_position", C.c_int32), ("pe_dropout", C.c_float),
+                ("tf_dropout", C.c_float), ("ln_eps", C.c_float), ("precision", C.c_int32)]
+
+
+# every symbol include/ge2e_hip.h declares: name -> (restype, argtypes)
+_PF = C.POINTER(C.c_float)
+_SIG = {
+    "ge2e_abi_version": (C.c_int, []),
+    "ge2e_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "ge2e_destroy": (C.c_int, [C.c_void_p]),
+    "ge2e_last_error": (C.c_char_p, [C.c_void_p]),
+    "ge2e_param_count": (C.c_int, [C.c_void_p]),
+    "ge2e_param_name": (C.c_char_p, [C.c_void_p, C.c_int]),
+    "ge2e_param_numel": (C.c_int64, [C.c_void_p, C.c_int]),
+    "ge2e_param_offset": (C.c_int64, [C.c_void_p, C.c_int]),
+    "ge2e_param_total": (C.c_int64, [C.c_void_p]),
+    "ge2e_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "ge2e_max_frames": (C.c_int, [C.c_void_p]),
+    "ge2e_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                       C.c_int, C.c_uint64, C.c_uint64]),
+    "ge2e_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                        C.c_uint64, C.c_uint64]),
+    "ge2e_encoder_backward_cb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_uint64, C.c_uint64, BUCKET_CB, C.c_void_p]),
+    "ge2e_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ge2e_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ge2e_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ge2e_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "ge2e_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ge2e_debug_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
+                                 C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ge2e_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int]),
+    "ge2e_drop_keep": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float]),
+}
+SYMBOLS = tuple(_SIG)
+
+
+def load():
+    """dlopen the in-tree library (built by __graft_entry__.build / _build.build)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB):
+                raise RuntimeError(
+                    f"{LIB} is missing: the GE2E HIP extension has not been built "
+                    "(run `python -m speaker_embedding_torch_amd._build`); there is no CPU fallback")
+            lib = C.CDLL(LIB)
+            for name, (res, args) in _SIG.items():
+                fn = getattr(lib, name)        # AttributeError if the ABI lost a symbol
+                fn.restype, fn.argtypes = res, args
+            if lib.ge2e_abi_version() != 1:
+                raise RuntimeError("libge2e_hip.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+class Handle:
+    """Owns one ge2e_handle; raises RuntimeError(ge2e_last_error) on any non-zero return."""
+
+    def __init__(self, mel_dim=80, emb=256, heads=4, layers=3, ffn=1024, max_position=1024,
+                 pe_dropout=0.1, tf_dropout=0.1, ln_eps=1e-5, precision=PREC_F32):
+        self.lib = load()
+        self.cfg = Config(mel_dim, emb, heads, layers, ffn, max_position, pe_dropout, tf_dropout, ln_eps, precision)
+        self._h = C.c_void_p()
+        rc = self.lib.ge2e_create(C.byref(self.cfg), C.byref(self._h))
+        if rc != 0:
+            raise RuntimeError(f"ge2e_create failed ({rc}): unsupported configuration "
+                               f"(emb must be 256 with 64-dim heads, ffn a multiple of 128)")
+        n = self.lib.ge2e_param_count(self._h)
+        self.param_names = [self.lib.ge2e_param_name(self._h, i).decode() for i in range(n)]
+        self.param_numel = [self.lib.ge2e_param_numel(self._h, i) for i in range(n)]
+        self.param_offset = [self.lib.ge2e_param_offset(self._h, i) for i in range(n)]
+        self.param_total = self.lib.ge2e_param_total(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self.lib.ge2e_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.ge2e_last_error(self._h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def workspace_bytes(self, n, t, train):
+        return self.lib.ge2e_workspace_bytes(self._h, n, t, 1 if train else 0)
+
+    def max_frames(self):
+        return self.lib.ge2e_max_frames(self._h)
+
+    def ptr_table(self, tensors):
+        arr = (C.c_void_p * len(tensors))()
+        for i, t in enumerate(tensors):
+            arr[i] = t.data_ptr()
+        return arr
+
+    def encoder_forward(self, stream, mel, n, t, samples, ptrs, pe, out, ws, train, seed, step):
+        self.check(self.lib.ge2e_encoder_forward(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, pe.data_ptr(),
+                                                 out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
+                                                 1 if train else 0, seed, step), "ge2e_encoder_forward")
+
+    def encoder_backward(self, stream, mel, n, t, samples, ptrs, d_emb, grads, ws, seed, step, cb=None):
+        if cb is None:
+            rc = self.lib.ge2e_encoder_backward(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, d_emb.data_ptr(),
+                                                grads.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(), seed, step)
+        else:
+            rc = self.lib.ge2e_encoder_backward_cb(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, d_emb.data_ptr(),
+                                                   grads.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
+                                                   seed, step, cb, None)
+        self.check(rc, "ge2e_encoder_backward")
+
+    def loss_workspace_bytes(self, speakers, utts):
+        return self.lib.ge2e_loss_workspace_bytes(speakers, utts, self.cfg.emb)
+
+    def loss_forward(self, stream, emb, speakers, utts, w, b, loss, ws):
+        self.check(self.lib.ge2e_loss_forward(self._h, stream, emb.data_ptr(), speakers, utts, w, b, loss.data_ptr(),
+                                              ws.data_ptr(), ws.numel() * ws.element_size()), "ge2e_loss_forward")
+
+    def loss_backward(self, stream, emb, speakers, utts, w, b, d_loss, d_emb, ws):
+        self.check(self.lib.ge2e_loss_backward(self._h, stream, emb.data_ptr(), speakers, utts, w, b, d_loss.data_ptr(),
+                                               d_emb.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size()),
+                   "ge2e_loss_backward")
+
+    def profile_enable(self, mask):
+        self.check(self.lib.ge2e_profile_enable(self._h, mask), "ge2e_profile_enable")
+
+    def profile_read(self, klass):
+        ms, work, cnt = C.c_double(), C.c_double(), C.c_int64()
+        self.check(self.lib.ge2e_profile_read(self._h, klass, C.byref(ms), C.byref(work), C.byref(cnt)), "ge2e_profile_read")
+        return ms.value, work.value, cnt.value
+
+    def debug_tap(self, name, n, t, train):
+        off, size = C.c_size_t(), C.c_size_t()
+        rc = self.lib.ge2e_debug_tap(self._h, name.encode(), n, t, 1 if train else 0, C.byref(off), C.byref(size))
+        if rc != 0:
+            raise KeyError(name)
+        return off.value, size.value

@@ -1,0 +1,283 @@
+// Fused self-attention of one (utterance, head): SURVEY.md 8a row a4 and its backward (a13).
+//
+// The whole key/value sequence of a head (T <= 32*KT frames, 64 dims) is LDS-resident; a wave owns
+// 16 query rows at a time.  Scores are computed TRANSPOSED (S^T = K Q^T) so that a query's row of
+// probabilities lives on one lane quartet and the probability accumulators feed the P.V MFMAs
+// directly as operands (no LDS round trip; guide section 3 "accumulator tile as the next operand").
+#pragma once
+#include "common.cuh"
+
+namespace ge2e {
+
+struct AttnArgs {
+    const void* qkv;     // [R, 3*D] of T : q | k | v, head h at columns h*64
+    void* o;             // fwd out   [R, D]
+    const void* dout;    // bwd in    [R, D]
+    void* dqkv;          // bwd out   [R, 3*D]
+    int T, H, D;
+    float scale;         // 1/sqrt(64)
+    Drop drop;           // dropout on the probabilities
+};
+
+template <typename T> __device__ __forceinline__ float exp_prec(float x);
+template <> __device__ __forceinline__ float exp_prec<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float exp_prec<bf16_t>(float x) { return __expf(x); }
+
+namespace attn {
+template <typename T> struct Geo {
+    static constexpr int ROWB = 64 * (int)sizeof(T);
+    static constexpr int LD = ROWB + 16;               // padded row (tile is read by rows and transposed)
+    static constexpr int CPR = ROWB / 16;
+    static constexpr int NKG = 64 / Prec<T>::KG;       // k-groups across the head dim
+};
+
+// cooperative load of `rows` x 64 head slice into a padded tile; rows >= T are zero
+template <typename T>
+__device__ __forceinline__ void load_tile(unsigned char* dst, const unsigned char* src, size_t src_ld_bytes,
+                                          int T_, int TP) {
+    using G = Geo<T>;
+    for (int id = threadIdx.x; id < TP * G::CPR; id += blockDim.x) {
+        const int row = id / G::CPR, c = id % G::CPR;
+        u32x4 v = u32x4{0, 0, 0, 0};
+        if (row < T_) v = *(const u32x4*)(src + (size_t)row * src_ld_bytes + c * 16);
+        *(u32x4*)(dst + row * G::LD + c * 16) = v;
+    }
+}
+// this lane's row fragments (row `row` of a [.,64] slice) straight from global memory
+template <typename T>
+__device__ __forceinline__ void load_row_frags(u32x4* f, const unsigned char* src, size_t src_ld_bytes, int row,
+                                               bool valid, int g) {
+    using G = Geo<T>;
+#pragma unroll
+    for (int k = 0; k < G::NKG; ++k)
+        f[k] = valid ? *(const u32x4*)(src + (size_t)row * src_ld_bytes + (k * 4 + g) * 16) : u32x4{0, 0, 0, 0};
+}
+// 16x16 tile of (tile rows x lane-owned rows): acc[r] = sum_d Tile[16*t + 4g + r][d] * f[lane row i][d]
+template <typename T>
+__device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, const u32x4* f, int i, int g) {
+    using G = Geo<T>;
+    f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < G::NKG; ++k)
+        acc = mma16<T>(lds16(tile + (16 * t + i) * G::LD + (k * 4 + g) * 16), f[k], acc);
+    return acc;
+}
+}  // namespace attn
+
+template <typename T, int KT>
+__global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
+    using G = attn::Geo<T>;
+    constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Ks = smem;
+    unsigned char* const Vs = smem + TP * G::LD;
+    const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const size_t ldq = (size_t)3 * p.D * sizeof(T);
+    const unsigned char* base = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
+    attn::load_tile<T>(Ks, base + (size_t)p.D * sizeof(T), ldq, p.T, TP);
+    attn::load_tile<T>(Vs, base + (size_t)2 * p.D * sizeof(T), ldq, p.T, TP);
+    __syncthreads();
+
+    for (int qt = wave; qt * 16 < p.T; qt += nw) {       // wave-uniform loop: EXEC stays full
+        const int qrow = qt * 16 + i;
+        const bool vq = qrow < p.T;
+        u32x4 qf[G::NKG];
+        attn::load_row_frags<T>(qf, base, ldq, qrow, vq, g);
+        f32x4 s[NT16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            s[t] = attn::tile_dot<T>(Ks, t, qf, i, g);   // S^T[key 16t+4g+r][query qrow]
+            __builtin_amdgcn_sched_barrier(0);   // keep live ranges per tile (VGPR 173 -> 91)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (16 * t + 4 * g + r) < p.T ? s[t][r] * p.scale : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = cross4_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
+        const float inv = 1.0f / cross4_sum(sum);
+        const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)p.T;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = drop_apply(p.drop, ibase + (uint32_t)(16 * t + 4 * g + r), s[t][r] * inv);
+
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)   // O^T[d = 16dt+4g+r][query] += V^T[d][keys] * P^T[keys][query]
+                oacc[dt] = mma16<T>(frag_tr<T>(Vs, G::LD, gi * KG, dt * 16, lane), pb, oacc[dt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (vq) {
+            T* orow = (T*)p.o + ((size_t)n * p.T + qrow) * p.D + h * 64 + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16, oacc[dt][0], oacc[dt][1], oacc[dt][2], oacc[dt][3]);
+        }
+    }
+}
+
+// Backward.  Phase A (wave owns 16 queries; K, V in LDS): recompute P, dP -> row stats (max, 1/sum, delta)
+// to LDS and dQ.  Phase B (wave owns 16 keys; Q, dO in LDS): recompute P and dS from the stats -> dK, dV.
+template <typename T, int KT>
+__global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
+    using G = attn::Geo<T>;
+    constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const bufA = smem;
+    unsigned char* const bufB = smem + TP * G::LD;
+    float* const st_m = (float*)(smem + 2 * TP * G::LD);
+    float* const st_l = st_m + TP;
+    float* const st_d = st_l + TP;
+    const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const size_t ldq = (size_t)3 * p.D * sizeof(T), ldo = (size_t)p.D * sizeof(T);
+    const unsigned char* qbase = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
+    const unsigned char* kbase = qbase + (size_t)p.D * sizeof(T);
+    const unsigned char* vbase = qbase + (size_t)2 * p.D * sizeof(T);
+    const unsigned char* dobase = (const unsigned char*)p.dout + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
+    T* const dq_out = (T*)p.dqkv + (size_t)n * p.T * 3 * p.D + h * 64;
+    const uint32_t hbase = (uint32_t)blockIdx.x * (uint32_t)p.T;
+
+    // ---------------------------------------------------------------- phase A
+    attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
+    attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
+    __syncthreads();
+    for (int qt = wave; qt * 16 < p.T; qt += nw) {
+        const int qrow = qt * 16 + i;
+        const bool vq = qrow < p.T;
+        u32x4 qf[G::NKG], dof[G::NKG];
+        attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
+        attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
+        f32x4 s[NT16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            s[t] = attn::tile_dot<T>(bufA, t, qf, i, g);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (16 * t + 4 * g + r) < p.T ? s[t][r] * p.scale : -INFINITY;
+                s[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = cross4_max(mx);
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
+        const float inv = 1.0f / cross4_sum(sum);
+        const uint32_t ibase = (hbase + (uint32_t)qrow) * (uint32_t)p.T;
+        f32x4 dp[NT16];
+        float delta = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            dp[t] = attn::tile_dot<T>(bufB, t, dof, i, g);     // d(P dropped)^T[key][query]
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = s[t][r] * inv;
+                const float dv = drop_apply(p.drop, ibase + (uint32_t)(16 * t + 4 * g + r), dp[t][r]);
+                s[t][r] = pr;
+                dp[t][r] = dv;
+                delta += pr * dv;
+            }
+        }
+        delta = cross4_sum(delta);
+        if (g == 0 && vq) { st_m[qrow] = mx; st_l[qrow] = inv; st_d[qrow] = delta; }
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - delta) * p.scale;   // dS^T (scaled)
+        f32x4 qacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) qacc[dt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const u32x4 sb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)   // dQ^T[d][query] += K^T[d][keys] * dS^T[keys][query]
+                qacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, qacc[dt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (vq) {
+            T* row = dq_out + (size_t)qrow * 3 * p.D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store4(row + dt * 16, qacc[dt][0], qacc[dt][1], qacc[dt][2], qacc[dt][3]);
+        }
+    }
+    __syncthreads();
+    // ---------------------------------------------------------------- phase B
+    attn::load_tile<T>(bufA, qbase, ldq, p.T, TP);
+    attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
+    __syncthreads();
+    for (int kt = wave; kt * 16 < p.T; kt += nw) {
+        const int krow = kt * 16 + i;
+        const bool vk = krow < p.T;
+        u32x4 kf[G::NKG], vf[G::NKG];
+        attn::load_row_frags<T>(kf, kbase, ldq, krow, vk, g);
+        attn::load_row_frags<T>(vf, vbase, ldq, krow, vk, g);
+        f32x4 kacc[4], vacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            constexpr int TPG = KG / 16;                 // query tiles per k-group (2 bf16, 1 f32)
+            f32x4 pd[2], ds[2];
+#pragma unroll
+            for (int u = 0; u < TPG; ++u) {
+                const int t = gi * TPG + u;
+                const f32x4 sa = attn::tile_dot<T>(bufA, t, kf, i, g);    // S[query 16t+4g+r][key krow]
+                const f32x4 da = attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
+                __builtin_amdgcn_sched_barrier(0);
+                const f32x4 m4 = *(const f32x4*)(st_m + 16 * t + 4 * g);
+                const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = 16 * t + 4 * g + r;
+                    const bool ok = (q < p.T) && vk;
+                    const float pr = ok ? exp_prec<T>(sa[r] * p.scale - m4[r]) * l4[r] : 0.0f;
+                    const uint32_t idx = (hbase + (uint32_t)q) * (uint32_t)p.T + (uint32_t)krow;
+                    const float dv = ok ? drop_apply(p.drop, idx, da[r]) : 0.0f;
+                    pd[u][r] = drop_apply(p.drop, idx, pr);
+                    ds[u][r] = ok ? pr * (dv - d4[r]) * p.scale : 0.0f;
+                }
+            }
+            const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);
+            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                vacc[dt] = mma16<T>(frag_tr<T>(bufB, G::LD, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
+                kacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (vk) {
+            T* row = dq_out + (size_t)krow * 3 * p.D + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                store4(row + p.D + dt * 16, kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+                store4(row + 2 * p.D + dt * 16, vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+            }
+        }
+    }
+}
+
+}  // namespace ge2e

@@ -1,0 +1,200 @@
+// Shared device helpers for the GE2E hot-path kernels (gfx950 / CDNA4 only).
+//
+// Two arithmetic modes share every kernel template:
+//   T = float  : v_mfma_f32_16x16x4_f32   (exact fp32 fma chain; the <=1e-4 parity path)
+//   T = bf16_t : v_mfma_f32_16x16x32_bf16 (bf16 storage, fp32 accumulate; the throughput path)
+// An MFMA operand "fragment" is always 16 bytes per lane (4 f32 / 8 bf16); one "k-group" is the
+// 64 bytes of K that the four 16-lane groups of a wave cover together (16 f32 / 32 bf16 values).
+// So LDS tiles have the same BYTE layout in both modes and only `mma16` differs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ge2e {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+template <typename T> struct Prec;
+template <> struct Prec<float> {
+    static constexpr int FRAG = 4;   // elements per 16-byte fragment
+    static constexpr int KG = 16;    // k values per k-group
+};
+template <> struct Prec<bf16_t> {
+    static constexpr int FRAG = 8;
+    static constexpr int KG = 32;
+};
+
+// ---------------------------------------------------------------------------------------------
+// mma16: C[16x16] += A[16 x KG] * B[KG x 16].   Lane l = 16*g + i supplies A[row i][slots of g]
+// and B[slots of g][col i]; returns/accumulates acc[r] = C[row 4g + r][col i].
+// Slot -> k mapping is free as long as A and B agree (see frag_* helpers below).
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ f32x4 mma16(u32x4 a, u32x4 b, f32x4 c);
+
+template <> __device__ __forceinline__ f32x4 mma16<float>(u32x4 a, u32x4 b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    return c;
+}
+template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scalar conversions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
+    unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+// pack two accumulator tiles (bf16) / one tile (f32) into an MFMA operand fragment ("acc mapping":
+// slot j<4 <-> row 4g+j of tile 0, slot 4+j <-> row 4g+j of tile 1 (bf16); slot s <-> row 4g+s (f32)).
+template <typename T> __device__ __forceinline__ u32x4 pack_acc(f32x4 t0, f32x4 t1);
+template <> __device__ __forceinline__ u32x4 pack_acc<float>(f32x4 t0, f32x4) {
+    u32x4 r;
+    r.x = __float_as_uint(t0[0]); r.y = __float_as_uint(t0[1]);
+    r.z = __float_as_uint(t0[2]); r.w = __float_as_uint(t0[3]);
+    return r;
+}
+template <> __device__ __forceinline__ u32x4 pack_acc<bf16_t>(f32x4 t0, f32x4 t1) {
+    u32x4 r;
+    r.x = pack_bf16x2(t0[0], t0[1]); r.y = pack_bf16x2(t0[2], t0[3]);
+    r.z = pack_bf16x2(t1[0], t1[1]); r.w = pack_bf16x2(t1[2], t1[3]);
+    return r;
+}
+
+// 4 consecutive output elements of type T from 4 floats (8 B for bf16, 16 B for f32)
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+    *(f32x4*)p = f32x4{a, b, c, d};
+}
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+    u32x2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
+    *(u32x2*)p = v;
+}
+__device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    u32x2 v = *(const u32x2*)p;
+    f32x4 r;
+    r[0] = __uint_as_float(v.x << 16); r[1] = __uint_as_float(v.x & 0xFFFF0000u);
+    r[2] = __uint_as_float(v.y << 16); r[3] = __uint_as_float(v.y & 0xFFFF0000u);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS tiles.  "swizzled row tile": rows of ROWB bytes, 16-byte chunk c of row r stored at chunk
+// c ^ (r & 7) (ROWB == 128) or c ^ (r & 15) (ROWB % 256 == 0): conflict-free ds_read_b128 for the
+// MFMA row-fragment pattern (lane -> row i, chunk g).  "padded tile": plain rows with a 16-byte pad,
+// used where a tile is (also) read transposed.
+// ---------------------------------------------------------------------------------------------
+template <int ROWB> __device__ __forceinline__ int swz_off(int row, int chunk) {
+    static_assert(ROWB == 128 || ROWB % 256 == 0, "row bytes");
+    if constexpr (ROWB == 128) return row * ROWB + ((chunk ^ (row & 7)) << 4);
+    else return row * ROWB + ((chunk ^ (row & 15)) << 4);
+}
+__device__ __forceinline__ u32x4 lds16(const unsigned char* p) { return *(const u32x4*)p; }
+
+// transposed fragment ("acc mapping") from a plain row-major tile X[r][c] of T, row stride ld bytes:
+// lane (i, g) gets the values X[r0 + 4g + j][c0 + i] (j = 0..3) and, for bf16, X[r0 + 16 + 4g + j][c0 + i].
+template <typename T> __device__ __forceinline__ u32x4 frag_tr(const unsigned char* tile, int ld, int r0, int c0, int lane);
+template <> __device__ __forceinline__ u32x4 frag_tr<float>(const unsigned char* tile, int ld, int r0, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned char* p = tile + (r0 + 4 * g) * ld + (c0 + i) * 4;
+    u32x4 r;
+    r.x = *(const unsigned*)(p);
+    r.y = *(const unsigned*)(p + ld);
+    r.z = *(const unsigned*)(p + 2 * ld);
+    r.w = *(const unsigned*)(p + 3 * ld);
+    return r;
+}
+template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char* tile, int ld, int r0, int c0, int lane) {
+    // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of (row q, cols 4p..4p+3)
+    // of a 4x16 block and receives column (4q+p) of the 4 rows.  EXEC must be all ones.
+    const int i = lane & 15, g = lane >> 4;
+    const unsigned char* p = tile + (r0 + 4 * g + (i >> 2)) * ld + (c0 + 4 * (i & 3)) * 2;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * ld));
+    u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    return u32x4{l2.x, l2.y, h2.x, h2.y};
+}
+
+// ---------------------------------------------------------------------------------------------
+// counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep
+//   keep(idx) = (mix32((idx * 0x9E3779B1) ^ key) >> 8) >= thr,   thr = floor(p * 2^24)
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
+    return (mix32((idx * 0x9E3779B1u) ^ key) >> 8) >= thr;
+}
+struct Drop {            // thr == 0  <=>  dropout inactive (eval mode or p == 0)
+    uint32_t key, thr;
+    float scale;         // 1 / (1 - p)
+};
+__device__ __forceinline__ float drop_apply(const Drop& d, uint32_t idx, float v) {
+    if (d.thr == 0) return v;
+    return drop_keep(idx, d.key, d.thr) ? v * d.scale : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// reductions
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+// sum over the 16 lanes that share g = lane >> 4
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int m = 8; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+// sum / max over the 4 lanes that share i = lane & 15
+__device__ __forceinline__ float cross4_sum(float v) {
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float cross4_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64)); v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+// block-wide sum for blockDim.x == 256; `red` is 4 floats of LDS; every thread gets the result
+__device__ __forceinline__ float block256_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+// XCD-aware bijective block remap (guide T1): blocks b and b+8 share an XCD (speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+}  // namespace ge2e

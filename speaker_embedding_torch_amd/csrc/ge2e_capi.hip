@@ -1,0 +1,720 @@
+// libge2e_hip.so: C-ABI entry points (include/ge2e_hip.h) and the launch sequence of the GE2E hot path.
+// One encoder forward = weight prep + prenet GEMM + per layer {in_proj GEMM, fused attention,
+// out_proj GEMM+LN, FFN1 GEMM, FFN2 GEMM+LN} + tail.  Everything is enqueued on the caller's stream.
+#include "../../include/ge2e_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "attention.cuh"
+#include "gemm.cuh"
+#include "misc.cuh"
+
+using namespace ge2e;
+
+namespace {
+
+constexpr int MAX_LAYERS = 8;
+constexpr int MAX_KT = 9;                 // attention instantiated for T <= 32 * MAX_KT = 288 frames
+
+struct ParamInfo { std::string name; int64_t numel, offset; };
+
+}  // namespace
+
+struct ProfRec { int klass; hipEvent_t start, stop; double work; };
+
+struct ge2e_handle_s {
+    ge2e_config cfg;
+    std::vector<ParamInfo> params;
+    int64_t total = 0;
+    std::mutex mu;
+    std::string err;
+    int prof_mask = 0;                     // bench.py roofline leg (ge2e_profile_enable)
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+int fail(ge2e_handle h, int code, const std::string& msg) {
+    if (h) { std::lock_guard<std::mutex> g(h->mu); h->err = msg; }
+    return code;
+}
+int fail_hip(ge2e_handle h, hipError_t e, const char* what) {
+    return fail(h, (int)e, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// parameter table indices (reference GE2E.parameters() order)
+enum { P_PRENET_W = 0, P_PRENET_B = 1, P_ALPHA = 2, P_LAYER0 = 3 };
+enum { L_IN_W = 0, L_IN_B, L_OUT_W, L_OUT_B, L_L1_W, L_L1_B, L_L2_W, L_L2_B, L_N1_W, L_N1_B, L_N2_W, L_N2_B, L_COUNT };
+inline int lp(int l, int which) { return P_LAYER0 + L_COUNT * l + which; }
+inline int p_fn_w(const ge2e_config& c) { return P_LAYER0 + L_COUNT * c.layers; }
+inline int p_fn_b(const ge2e_config& c) { return p_fn_w(c) + 1; }
+inline int p_proj_w(const ge2e_config& c) { return p_fn_w(c) + 2; }
+inline int p_proj_b(const ge2e_config& c) { return p_fn_w(c) + 3; }
+
+void build_params(ge2e_handle h) {
+    const ge2e_config& c = h->cfg;
+    auto add = [&](const std::string& n, int64_t numel) { h->params.push_back({n, numel, h->total}); h->total += numel; };
+    const int64_t d = c.emb, f = c.ffn;
+    add("prenet.weight", d * c.mel_dim); add("prenet.bias", d); add("positional_encoding.alpha", 1);
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = "transformer.layers." + std::to_string(l) + ".";
+        add(p + "self_attn.in_proj_weight", 3 * d * d); add(p + "self_attn.in_proj_bias", 3 * d);
+        add(p + "self_attn.out_proj.weight", d * d); add(p + "self_attn.out_proj.bias", d);
+        add(p + "linear1.weight", f * d); add(p + "linear1.bias", f);
+        add(p + "linear2.weight", d * f); add(p + "linear2.bias", d);
+        add(p + "norm1.weight", d); add(p + "norm1.bias", d);
+        add(p + "norm2.weight", d); add(p + "norm2.bias", d);
+    }
+    add("transformer.norm.weight", d); add("transformer.norm.bias", d);
+    add("projection.weight", d * d); add("projection.bias", d);
+}
+
+// ------------------------------------------------------------------------------------------ workspace
+struct Layout {
+    size_t esz = 0;
+    int R = 0, KP = 0;
+    size_t w_prenet = 0, w_in[MAX_LAYERS], w_inT[MAX_LAYERS], w_out[MAX_LAYERS], w_outT[MAX_LAYERS];
+    size_t w_l1[MAX_LAYERS], w_l1T[MAX_LAYERS], w_l2[MAX_LAYERS], w_l2T[MAX_LAYERS];
+    size_t wqT = 0, pe_t = 0, h0 = 0;
+    size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
+    size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
+    size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
+    size_t total = 0;
+};
+
+Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_max = 1) {
+    (void)samples_max;
+    Layout L;
+    L.esz = c.precision == GE2E_PREC_BF16 ? 2 : 4;
+    const int BK = 128 / (int)L.esz;
+    L.KP = (c.mel_dim + BK - 1) / BK * BK;
+    L.R = n * t;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t d = c.emb, f = c.ffn, R = (size_t)L.R, e = L.esz;
+    L.w_prenet = take(d * L.KP * e);
+    for (int l = 0; l < c.layers; ++l) {
+        L.w_in[l] = take(3 * d * d * e);  L.w_inT[l] = take(3 * d * d * e);
+        L.w_out[l] = take(d * d * e);     L.w_outT[l] = take(d * d * e);
+        L.w_l1[l] = take(f * d * e);      L.w_l1T[l] = take(f * d * e);
+        L.w_l2[l] = take(f * d * e);      L.w_l2T[l] = take(f * d * e);
+    }
+    L.wqT = take(d * d * 4);
+    L.pe_t = take((size_t)t * d * 4);
+    L.h0 = take(R * d * e);
+    if (train) {
+        for (int l = 0; l < c.layers; ++l) {
+            L.qkv[l] = take(R * 3 * d * e); L.o[l] = take(R * d * e);
+            L.h1[l] = take(R * d * e);      L.rstd1[l] = take(R * 4);
+            L.f[l] = take(R * f * e);       L.h2[l] = take(R * d * e);
+            L.rstd2[l] = take(R * 4);
+        }
+    } else {        // eval: layers reuse one set of buffers; h2 overwrites the layer input
+        const size_t qkv = take(R * 3 * d * e), o = take(R * d * e), h1 = take(R * d * e), ff = take(R * f * e);
+        for (int l = 0; l < c.layers; ++l) {
+            L.qkv[l] = qkv; L.o[l] = o; L.h1[l] = h1; L.f[l] = ff; L.h2[l] = L.h0;
+            L.rstd1[l] = L.rstd2[l] = (size_t)-1;
+        }
+    }
+    L.xhat_f = take((size_t)n * d * 4); L.rstd_f = take((size_t)n * 4);
+    L.zm = take((size_t)n * d * 4);     L.nrm = take((size_t)n * 4);
+    L.emb_keep = take((size_t)n * d * 4); L.d_raw = take((size_t)n * d * 4);
+    if (train) {
+        L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dP = take(R * d * e); L.dM = take(R * d * e);
+        L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
+    }
+    L.total = off;
+    return L;
+}
+
+Drop make_drop(bool active, float p, uint64_t seed, uint64_t step, int site) {
+    Drop d{0u, 0u, 1.0f};
+    if (!active || p <= 0.0f) return d;
+    d.key = ge2e_drop_key(seed, step, site);
+    d.thr = (uint32_t)std::floor((double)p * 16777216.0);
+    d.scale = (float)(1.0 / (1.0 - (double)p));
+    return d;
+}
+enum { SITE_PE = 0 };
+inline int site_attn(int l) { return 1 + 4 * l; }
+inline int site_sa(int l) { return 2 + 4 * l; }
+inline int site_ffh(int l) { return 3 + 4 * l; }
+inline int site_ff(int l) { return 4 + 4 * l; }
+
+// brackets one launch with events on its stream when its class is being profiled
+struct ProfScope {
+    ge2e_handle h; hipStream_t st; bool on = false; ProfRec rec{};
+    ProfScope(ge2e_handle h_, hipStream_t st_, int klass, double work) : h(h_), st(st_) {
+        if (!(h->prof_mask & klass)) return;
+        auto get = [&]() { hipEvent_t e = nullptr;
+            if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+            return e; };
+        std::lock_guard<std::mutex> g(h->mu);
+        rec.klass = klass; rec.work = work; rec.start = get(); rec.stop = get();
+        on = rec.start && rec.stop;
+        if (on) hipEventRecord(rec.start, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        hipEventRecord(rec.stop, st);
+        std::lock_guard<std::mutex> g(h->mu);
+        h->prof.push_back(rec);
+    }
+};
+
+// ------------------------------------------------------------------------------------------ launches
+#define GE2E_LAUNCH(h, kern, grid, block, smem, st, ...)                                                   \
+    do {                                                                                                    \
+        static bool attr_done = false;                                                                      \
+        if (!attr_done && (size_t)(smem) > (size_t)48 * 1024) {  /* per call site: smem is a compile-time constant there */ \
+            hipError_t ea = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)); \
+            if (ea != hipSuccess) return fail_hip(h, ea, "hipFuncSetAttribute " #kern);                     \
+            attr_done = true;                                                                               \
+        }                                                                                                   \
+        hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                       \
+        hipError_t el = hipGetLastError();                                                                  \
+        if (el != hipSuccess) return fail_hip(h, el, #kern);                                                \
+    } while (0)
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD>
+int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
+    constexpr int BK = 128 / (int)sizeof(T);
+    if (a.K % BK != 0 || a.N % BN != 0 || a.M <= 0)
+        return fail(h, GE2E_EUNSUPPORTED, "gemm: N must be a multiple of the tile and K of the k-step");
+    const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const size_t smem = 2 * (size_t)(BM + BN) * 128;
+    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD>;
+    ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM,
+                 2.0 * a.M * a.N * (ALOAD == ALOAD_MEL ? a.mel : a.K));
+    GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), smem, st, a);
+    return 0;
+}
+template <typename T, int EPI, int ALOAD = ALOAD_ROW>
+int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD>(h, st, a); }
+template <typename T>
+int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 128, 256, 32, 256, EPI_LN, ALOAD_ROW>(h, st, a); }
+
+template <typename T, int XLOAD>
+int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
+    constexpr int RS = 2 * Prec<T>::KG;
+    constexpr int LD = 128 * (int)sizeof(T) + 16;
+    if (a.N % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: N must be a multiple of 128");
+    if (XLOAD == ALOAD_ROW && a.K % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: K must be a multiple of 128");
+    const int tn = a.N / 128, tk = (a.K + 127) / 128;
+    int splits = (1024 + tn * tk - 1) / (tn * tk);
+    const int max_splits = (a.R + 4 * RS - 1) / (4 * RS);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    int rps = (a.R + splits - 1) / splits;
+    rps = (rps + RS - 1) / RS * RS;
+    splits = (a.R + rps - 1) / rps;
+    a.rows_per_split = rps;
+    const size_t smem = 4 * (size_t)RS * LD;
+    auto kern = wgrad_kernel<T, XLOAD>;
+    ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * a.R * a.N * a.K);
+    GE2E_LAUNCH(h, kern, dim3(tn, tk, splits), dim3(256), smem, st, a);
+    return 0;
+}
+
+template <typename T, int KT>
+int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
+    using G = attn::Geo<T>;
+    constexpr int TP = 32 * KT;
+    const int qtiles = (a.T + 15) / 16;
+    int nw = (qtiles + 1) / 2;
+    if (nw > 8) nw = 8;
+    if (nw < 1) nw = 1;
+    const dim3 grid(n * a.H), block(64 * nw);
+    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H);
+    if (!bwd) {
+        const size_t smem = 2 * (size_t)TP * G::LD;
+        auto kern = attn_fwd_kernel<T, KT>;
+        GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
+    } else {
+        const size_t smem = 2 * (size_t)TP * G::LD + 3 * (size_t)TP * 4;
+        auto kern = attn_bwd_kernel<T, KT>;
+        GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
+    }
+    return 0;
+}
+template <typename T>
+int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
+    switch ((a.T + 31) / 32) {
+        case 1: return launch_attn_kt<T, 1>(h, st, a, n, bwd);
+        case 2: return launch_attn_kt<T, 2>(h, st, a, n, bwd);
+        case 3: return launch_attn_kt<T, 3>(h, st, a, n, bwd);
+        case 4: return launch_attn_kt<T, 4>(h, st, a, n, bwd);
+        case 5: return launch_attn_kt<T, 5>(h, st, a, n, bwd);
+        case 6: return launch_attn_kt<T, 6>(h, st, a, n, bwd);
+        case 7: return launch_attn_kt<T, 7>(h, st, a, n, bwd);
+        case 8: return launch_attn_kt<T, 8>(h, st, a, n, bwd);
+        case 9: return launch_attn_kt<T, 9>(h, st, a, n, bwd);
+        default: return fail(h, GE2E_EUNSUPPORTED, "attention: frames > 288 not instantiated");
+    }
+}
+
+int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_t ws_bytes, const Layout& L) {
+    const ge2e_config& c = h->cfg;
+    if (n <= 0 || t <= 0 || samples <= 0 || n % samples != 0) return fail(h, GE2E_EINVAL, "n_utts/frames/samples invalid");
+    if (t > 32 * MAX_KT) return fail(h, GE2E_EUNSUPPORTED, "frames > 288 not supported by the attention kernels");
+    if (t > c.max_position) return fail(h, GE2E_EINVAL, "frames > max_position");
+    if ((double)n * t * c.ffn >= 4294967296.0) return fail(h, GE2E_EUNSUPPORTED, "n_utts*frames*ffn must stay below 2^32 (dropout counters)");
+    if (!ws || ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "workspace too small (see ge2e_workspace_bytes)");
+    if (((uintptr_t)ws & 255) != 0) return fail(h, GE2E_EINVAL, "workspace must be 256-byte aligned");
+    return 0;
+}
+
+#define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+template <typename T>
+int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
+                 const float* const* P, const float* pe, float* out_emb, unsigned char* ws, const Layout& L,
+                 bool train, uint64_t seed, uint64_t step) {
+    const ge2e_config& c = h->cfg;
+    const int d = c.emb, R = L.R;
+    // ---- weight preparation (fp32 masters -> T copies, transposed copies for dgrad)
+    {
+        std::vector<PrepJob> jobs;
+        auto add = [&](const float* src, size_t dst, size_t dstT, int rows, int cols, int ldd) {
+            PrepJob j{src, ws + dst, (train && dstT != (size_t)-1) ? ws + dstT : nullptr, rows, cols, ldd, 0, (ldd + 31) / 32};
+            jobs.push_back(j);
+        };
+        add(P[P_PRENET_W], L.w_prenet, (size_t)-1, d, c.mel_dim, L.KP);
+        for (int l = 0; l < c.layers; ++l) {
+            add(P[lp(l, L_IN_W)], L.w_in[l], L.w_inT[l], 3 * d, d, d);
+            add(P[lp(l, L_OUT_W)], L.w_out[l], L.w_outT[l], d, d, d);
+            add(P[lp(l, L_L1_W)], L.w_l1[l], L.w_l1T[l], c.ffn, d, d);
+            add(P[lp(l, L_L2_W)], L.w_l2[l], L.w_l2T[l], d, c.ffn, c.ffn);
+        }
+        for (size_t b = 0; b < jobs.size(); b += PREP_MAX_JOBS) {
+            PrepArgs a{};
+            a.njobs = (int)std::min<size_t>(PREP_MAX_JOBS, jobs.size() - b);
+            int tiles = 0;
+            for (int q = 0; q < a.njobs; ++q) {
+                a.job[q] = jobs[b + q];
+                a.job[q].tile0 = tiles;
+                tiles += a.job[q].tiles_x * ((a.job[q].rows + 31) / 32);
+            }
+            auto kern = prep_weights_kernel<T>;
+            GE2E_LAUNCH(h, kern, dim3(tiles), dim3(256), 0, st, a);
+        }
+        GE2E_LAUNCH(h, transpose_f32_kernel, dim3((t + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
+                    pe, (float*)(ws + L.pe_t), d, c.max_position, t);
+        GE2E_LAUNCH(h, transpose_f32_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
+                    P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
+    }
+    // ---- prenet + ReLU + positional encoding (+ dropout)
+    {
+        GemmArgs a{};
+        a.A = mel; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.h0; a.ldc = d;
+        a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
+        a.drop = make_drop(train, c.pe_dropout, seed, step, SITE_PE);
+        a.pe_t = (const float*)(ws + L.pe_t); a.alpha = P[P_ALPHA]; a.T = t; a.mel = c.mel_dim;
+        CK((gemm128<T, EPI_PRENET, ALOAD_MEL>(h, st, a)));
+    }
+    for (int l = 0; l < c.layers; ++l) {
+        unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
+        {   // in_proj
+            GemmArgs a{};
+            a.A = hin; a.lda = d; a.W = ws + L.w_in[l]; a.ldw = d; a.C = ws + L.qkv[l]; a.ldc = 3 * d;
+            a.M = R; a.N = 3 * d; a.K = d; a.bias = P[lp(l, L_IN_B)];
+            CK((gemm128<T, EPI_BIAS>(h, st, a)));
+        }
+        {   // softmax(q k^T / 8) v per (utterance, head)
+            AttnArgs a{};
+            a.qkv = ws + L.qkv[l]; a.o = ws + L.o[l]; a.T = t; a.H = c.heads; a.D = d;
+            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
+            CK(launch_attn<T>(h, st, a, n, false));
+        }
+        {   // out_proj + dropout1 + residual + norm1
+            GemmArgs a{};
+            a.A = ws + L.o[l]; a.lda = d; a.W = ws + L.w_out[l]; a.ldw = d; a.C = ws + L.h1[l]; a.ldc = d;
+            a.M = R; a.N = d; a.K = d; a.bias = P[lp(l, L_OUT_B)]; a.R = hin; a.ldr = d;
+            a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)]; a.eps = c.ln_eps;
+            a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l));
+            CK(gemm_ln<T>(h, st, a));
+        }
+        {   // linear1 + ReLU + dropout
+            GemmArgs a{};
+            a.A = ws + L.h1[l]; a.lda = d; a.W = ws + L.w_l1[l]; a.ldw = d; a.C = ws + L.f[l]; a.ldc = c.ffn;
+            a.M = R; a.N = c.ffn; a.K = d; a.bias = P[lp(l, L_L1_B)];
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
+            CK((gemm128<T, EPI_BIAS_RELU_DROP>(h, st, a)));
+        }
+        {   // linear2 + dropout2 + residual + norm2
+            GemmArgs a{};
+            a.A = ws + L.f[l]; a.lda = c.ffn; a.W = ws + L.w_l2[l]; a.ldw = c.ffn; a.C = ws + L.h2[l]; a.ldc = d;
+            a.M = R; a.N = d; a.K = c.ffn; a.bias = P[lp(l, L_L2_B)]; a.R = ws + L.h1[l]; a.ldr = d;
+            a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)]; a.eps = c.ln_eps;
+            a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ff(l));
+            CK(gemm_ln<T>(h, st, a));
+        }
+    }
+    {   // final LN at t = 0 -> slice mean -> projection -> L2 normalise
+        TailArgs a{};
+        a.h = ws + L.h2[c.layers - 1]; a.T = t; a.samples = samples; a.N = n;
+        a.gf = P[p_fn_w(c)]; a.bf = P[p_fn_b(c)]; a.wq = P[p_proj_w(c)]; a.wqT = (const float*)(ws + L.wqT); a.bq = P[p_proj_b(c)];
+        a.eps = c.ln_eps;
+        a.xhat = (float*)(ws + L.xhat_f); a.rstd = (float*)(ws + L.rstd_f);
+        a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm);
+        a.emb = (float*)(ws + L.emb_keep);
+        auto kern = tail_fwd_kernel<T>;
+        GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
+        hipError_t e = hipMemcpyAsync(out_emb, ws + L.emb_keep, (size_t)(n / samples) * d * 4, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return fail_hip(h, e, "copy embeddings");
+    }
+    return 0;
+}
+
+template <typename T>
+int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
+                  const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
+                  uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user) {
+    const ge2e_config& c = h->cfg;
+    const int d = c.emb, R = L.R;
+    auto G = [&](int idx) { return grads + h->params[idx].offset; };
+    auto bucket = [&](int first, int last) {   // parameters [first, last] are final: tell the caller
+        if (cb) cb(user, h->params[first].offset, h->params[last].offset + h->params[last].numel - h->params[first].offset);
+    };
+    hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
+    if (e != hipSuccess) return fail_hip(h, e, "zero grads");
+    e = hipMemsetAsync(ws + L.dHa, 0, (size_t)R * d * L.esz, st);
+    if (e != hipSuccess) return fail_hip(h, e, "zero dH");
+    {
+        TailArgs a{};
+        a.T = t; a.samples = samples; a.N = n;
+        a.gf = P[p_fn_w(c)]; a.bf = P[p_fn_b(c)]; a.wq = P[p_proj_w(c)]; a.bq = P[p_proj_b(c)];
+        a.xhat = (float*)(ws + L.xhat_f); a.rstd = (float*)(ws + L.rstd_f);
+        a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm); a.emb = (float*)(ws + L.emb_keep);
+        a.d_emb = d_emb; a.d_raw = (float*)(ws + L.d_raw); a.dH = ws + L.dHa;
+        a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dwq = G(p_proj_w(c)); a.dbq = G(p_proj_b(c));
+        auto kern = tail_bwd_kernel<T>;
+        GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
+        GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d), dim3(256), 0, st, a);
+        bucket(p_fn_w(c), p_proj_b(c));
+    }
+    const int ln_grid = std::min(2048, (R + 3) / 4);
+    // diagnostics only: GE2E_DEBUG_BWD_STOP=k returns after k layers so ge2e_debug_tap sees that layer's scratch
+    const char* dbg_stop = std::getenv("GE2E_DEBUG_BWD_STOP");
+    const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
+    for (int l = c.layers - 1; l >= 0; --l) {
+        if (stop_after >= 0 && c.layers - 1 - l >= stop_after) return 0;
+        unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
+        const Drop d_ff = make_drop(true, c.tf_dropout, seed, step, site_ff(l));
+        const Drop d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
+        const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
+        {   // norm2 backward
+            LnBwdArgs a{};
+            a.dy = ws + L.dHa; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
+            a.rstd = (const float*)(ws + L.rstd2[l]); a.dpre = ws + L.dP; a.dmask = d_ff.thr ? ws + L.dM : nullptr;
+            a.dgamma = G(lp(l, L_N2_W)); a.dbeta = G(lp(l, L_N2_B)); a.R = R; a.drop = d_ff;
+            auto kern = ln_bwd_kernel<T>;
+            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)R * d * L.esz * (d_ff.thr ? 4 : 3));
+            GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
+        }
+        unsigned char* gm = ws + (d_ff.thr ? L.dM : L.dP);
+        {   // dF = (dG W2) masked by ReLU/dropout of the hidden
+            GemmArgs a{};
+            a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = ws + L.dF; a.ldc = c.ffn;
+            a.M = R; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
+            CK((gemm128<T, EPI_MASK>(h, st, a)));
+        }
+        {
+            WgradArgs a{};
+            a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
+            a.R = R; a.N = d; a.K = c.ffn;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+        }
+        {
+            WgradArgs a{};
+            a.Y = ws + L.dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
+            a.R = R; a.N = c.ffn; a.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+        }
+        {   // dH1 = dPre2 + dF W1
+            GemmArgs a{};
+            a.A = ws + L.dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = ws + L.dHb; a.ldc = d;
+            a.M = R; a.N = d; a.K = c.ffn; a.R = ws + L.dP; a.ldr = d;
+            CK((gemm128<T, EPI_ADD>(h, st, a)));
+        }
+        {   // norm1 backward
+            LnBwdArgs a{};
+            a.dy = ws + L.dHb; a.y = ws + L.h1[l]; a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)];
+            a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = ws + L.dP; a.dmask = d_sa.thr ? ws + L.dM : nullptr;
+            a.dgamma = G(lp(l, L_N1_W)); a.dbeta = G(lp(l, L_N1_B)); a.R = R; a.drop = d_sa;
+            auto kern = ln_bwd_kernel<T>;
+            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)R * d * L.esz * (d_sa.thr ? 4 : 3));
+            GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
+        }
+        gm = ws + (d_sa.thr ? L.dM : L.dP);
+        {   // dO = dA Wo
+            GemmArgs a{};
+            a.A = gm; a.lda = d; a.W = ws + L.w_outT[l]; a.ldw = d; a.C = ws + L.dO; a.ldc = d;
+            a.M = R; a.N = d; a.K = d;
+            CK((gemm128<T, EPI_NONE>(h, st, a)));
+        }
+        {
+            WgradArgs a{};
+            a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
+            a.R = R; a.N = d; a.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+        }
+        {
+            AttnArgs a{};
+            a.qkv = ws + L.qkv[l]; a.dout = ws + L.dO; a.dqkv = ws + L.dQKV; a.T = t; a.H = c.heads; a.D = d;
+            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
+            a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
+            CK(launch_attn<T>(h, st, a, n, true));
+        }
+        {
+            WgradArgs a{};
+            a.Y = ws + L.dQKV; a.ldy = 3 * d; a.X = hin; a.ldx = d; a.dW = G(lp(l, L_IN_W)); a.ldw = d; a.db = G(lp(l, L_IN_B));
+            a.R = R; a.N = 3 * d; a.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+        }
+        {   // dH(layer input) = dPre1 + dQKV Win
+            GemmArgs a{};
+            a.A = ws + L.dQKV; a.lda = 3 * d; a.W = ws + L.w_inT[l]; a.ldw = 3 * d; a.C = ws + L.dHa; a.ldc = d;
+            a.M = R; a.N = d; a.K = 3 * d; a.R = ws + L.dP; a.ldr = d;
+            CK((gemm128<T, EPI_ADD>(h, st, a)));
+        }
+        bucket(lp(l, 0), lp(l, L_COUNT - 1));
+    }
+    {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place
+        GemmArgs a{};
+        a.A = mel; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.dHa; a.ldc = d; a.R = ws + L.dHa; a.ldr = d;
+        a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
+        a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
+        a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
+        CK((gemm128<T, EPI_PRENET_BWD, ALOAD_MEL>(h, st, a)));
+        WgradArgs w{};
+        w.Y = ws + L.dHa; w.ldy = d; w.X = mel; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
+        w.R = R; w.N = d; w.K = c.mel_dim; w.T = t; w.mel = c.mel_dim;
+        CK((launch_wgrad<T, ALOAD_MEL>(h, st, w)));
+        bucket(P_PRENET_W, P_ALPHA);
+    }
+    return 0;
+}
+
+struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, total; };
+LossLayout loss_layout(int S, int P, int d) {
+    LossLayout L{};
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
+    const size_t N = (size_t)S * P;
+    L.cent = take((size_t)S * d); L.cn = take(S); L.en = take(N); L.rowloss = take(N);
+    L.G = take(N * S); L.cosm = take(N * S); L.dC = take((size_t)S * d);
+    L.total = off;
+    return L;
+}
+LossArgs loss_args(const float* emb, int S, int P, float w, float b, unsigned char* ws, const LossLayout& L) {
+    LossArgs a{};
+    a.emb = emb; a.N = S * P; a.S = S; a.P = P; a.w = w; a.b = b;
+    a.cent = (float*)(ws + L.cent); a.cn = (float*)(ws + L.cn); a.en = (float*)(ws + L.en);
+    a.rowloss = (float*)(ws + L.rowloss); a.G = (float*)(ws + L.G); a.cosm = (float*)(ws + L.cosm); a.dC = (float*)(ws + L.dC);
+    return a;
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int ge2e_abi_version(void) { return GE2E_ABI_VERSION; }
+
+int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
+    if (!cfg || !out) return GE2E_EINVAL;
+    *out = nullptr;
+    if (cfg->emb != 256 || cfg->heads <= 0 || cfg->emb / cfg->heads != 64 || cfg->emb % cfg->heads != 0) return GE2E_EUNSUPPORTED;
+    if (cfg->layers < 1 || cfg->layers > MAX_LAYERS || cfg->mel_dim < 1 || cfg->mel_dim > 128) return GE2E_EUNSUPPORTED;
+    if (cfg->ffn % 128 != 0 || cfg->ffn < 128 || cfg->max_position < 1) return GE2E_EUNSUPPORTED;
+    if (cfg->precision != GE2E_PREC_F32 && cfg->precision != GE2E_PREC_BF16) return GE2E_EINVAL;
+    if (cfg->pe_dropout < 0.f || cfg->pe_dropout >= 1.f || cfg->tf_dropout < 0.f || cfg->tf_dropout >= 1.f) return GE2E_EINVAL;
+    ge2e_handle h = new (std::nothrow) ge2e_handle_s();
+    if (!h) return GE2E_EINVAL;
+    h->cfg = *cfg;
+    build_params(h);
+    *out = h;
+    return 0;
+}
+
+int ge2e_destroy(ge2e_handle h) { delete h; return 0; }
+
+const char* ge2e_last_error(ge2e_handle h) {
+    if (!h) return "null handle";
+    std::lock_guard<std::mutex> g(h->mu);
+    static thread_local std::string copy;
+    copy = h->err;
+    return copy.c_str();
+}
+
+int ge2e_param_count(ge2e_handle h) { return h ? (int)h->params.size() : GE2E_EINVAL; }
+const char* ge2e_param_name(ge2e_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr; }
+int64_t ge2e_param_numel(ge2e_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].numel : -1; }
+int64_t ge2e_param_offset(ge2e_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].offset : -1; }
+int64_t ge2e_param_total(ge2e_handle h) { return h ? h->total : -1; }
+int ge2e_max_frames(ge2e_handle h) { (void)h; return 32 * MAX_KT; }
+
+size_t ge2e_workspace_bytes(ge2e_handle h, int n_utts, int frames, int train) {
+    if (!h || n_utts <= 0 || frames <= 0) return 0;
+    return build_layout(h->cfg, n_utts, frames, train).total;
+}
+
+int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                         const float* const* params, const float* pe, float* out_emb,
+                         void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step) {
+    if (!h) return GE2E_EINVAL;
+    if (!mel || !params || !pe || !out_emb) return fail(h, GE2E_EINVAL, "null pointer argument");
+    for (size_t i = 0; i < h->params.size(); ++i)
+        if (!params[i]) return fail(h, GE2E_EINVAL, "null parameter pointer: " + h->params[i].name);
+    const Layout L = build_layout(h->cfg, n_utts, frames, train);
+    CK(check_common(h, n_utts, frames, samples, workspace, workspace_bytes, L));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    if (h->cfg.precision == GE2E_PREC_BF16)
+        return forward_impl<bf16_t>(h, st, mel, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+    return forward_impl<float>(h, st, mel, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+}
+
+int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                          const float* const* params, const float* d_emb, float* grads_flat,
+                          void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step) {
+    return ge2e_encoder_backward_cb(h, stream, mel, n_utts, frames, samples, params, d_emb, grads_flat,
+                                    workspace, workspace_bytes, seed, step, nullptr, nullptr);
+}
+
+int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                             const float* const* params, const float* d_emb, float* grads_flat,
+                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
+                             ge2e_bucket_cb cb, void* user) {
+    if (!h) return GE2E_EINVAL;
+    if (!mel || !params || !d_emb || !grads_flat) return fail(h, GE2E_EINVAL, "null pointer argument");
+    for (size_t i = 0; i < h->params.size(); ++i)
+        if (!params[i]) return fail(h, GE2E_EINVAL, "null parameter pointer: " + h->params[i].name);
+    const Layout L = build_layout(h->cfg, n_utts, frames, 1);
+    CK(check_common(h, n_utts, frames, samples, workspace, workspace_bytes, L));
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    if (h->cfg.precision == GE2E_PREC_BF16)
+        return backward_impl<bf16_t>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
+    return backward_impl<float>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
+}
+
+size_t ge2e_loss_workspace_bytes(int speakers, int utts, int emb) {
+    if (speakers <= 0 || utts <= 0 || emb <= 0) return 0;
+    return loss_layout(speakers, utts, emb).total;
+}
+
+int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
+                      float w, float b, float* loss, void* loss_ws, size_t loss_ws_bytes) {
+    if (!h) return GE2E_EINVAL;
+    if (!emb || !loss || !loss_ws || speakers <= 0 || utts <= 0) return fail(h, GE2E_EINVAL, "loss: bad argument");
+    if (speakers > 8192) return fail(h, GE2E_EUNSUPPORTED, "loss: more than 8192 speakers per batch");
+    const LossLayout L = loss_layout(speakers, utts, h->cfg.emb);
+    if (loss_ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "loss workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
+    a.loss = loss;
+    GE2E_LAUNCH(h, loss_centroid_kernel, dim3(speakers), dim3(256), 0, st, a);
+    GE2E_LAUNCH(h, loss_row_kernel, dim3(a.N), dim3(256), (size_t)2 * speakers * 4, st, a);
+    GE2E_LAUNCH(h, loss_reduce_kernel, dim3(1), dim3(256), 0, st, a);
+    return 0;
+}
+
+int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
+                       float w, float b, const float* d_loss, float* d_emb, void* loss_ws, size_t loss_ws_bytes) {
+    if (!h) return GE2E_EINVAL;
+    if (!emb || !d_loss || !d_emb || !loss_ws || speakers <= 0 || utts <= 0) return fail(h, GE2E_EINVAL, "loss: bad argument");
+    const LossLayout L = loss_layout(speakers, utts, h->cfg.emb);
+    if (loss_ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "loss workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
+    a.gscale = d_loss; a.d_emb = d_emb;
+    GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers), dim3(256), 0, st, a);
+    GE2E_LAUNCH(h, loss_bwd_row_kernel, dim3(a.N), dim3(256), 0, st, a);
+    return 0;
+}
+
+int ge2e_profile_enable(ge2e_handle h, int class_mask) {
+    if (!h) return GE2E_EINVAL;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->prof_mask = class_mask;
+    return 0;
+}
+
+int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, int64_t* launches) {
+    if (!h || !total_ms || !total_work || !launches) return GE2E_EINVAL;
+    std::vector<ProfRec> mine, rest;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        for (auto& r : h->prof) (r.klass == klass ? mine : rest).push_back(r);
+        h->prof.swap(rest);
+    }
+    double ms = 0.0, work = 0.0;
+    for (auto& r : mine) {
+        hipError_t e = hipEventSynchronize(r.stop);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, r.start, r.stop);
+        if (e != hipSuccess) return fail_hip(h, e, "profile event");
+        ms += t; work += r.work;
+    }
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        for (auto& r : mine) { h->ev_pool.push_back(r.start); h->ev_pool.push_back(r.stop); }
+    }
+    *total_ms = ms; *total_work = work; *launches = (int64_t)mine.size();
+    return 0;
+}
+
+int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int train,
+                   size_t* offset_bytes, size_t* size_bytes) {
+    if (!h || !name || !offset_bytes || !size_bytes) return GE2E_EINVAL;
+    const Layout L = build_layout(h->cfg, n_utts, frames, train);
+    const size_t R = (size_t)L.R, d = h->cfg.emb, e = L.esz;
+    std::string s(name);
+    int l = 0;
+    const size_t dot = s.find('.');
+    std::string base = s;
+    if (dot != std::string::npos) { base = s.substr(0, dot); l = std::atoi(s.c_str() + dot + 1); }
+    if (l < 0 || l >= h->cfg.layers) return GE2E_EINVAL;
+    if (base == "h0") { *offset_bytes = L.h0; *size_bytes = R * d * e; }
+    else if (base == "qkv") { *offset_bytes = L.qkv[l]; *size_bytes = R * 3 * d * e; }
+    else if (base == "o") { *offset_bytes = L.o[l]; *size_bytes = R * d * e; }
+    else if (base == "h1") { *offset_bytes = L.h1[l]; *size_bytes = R * d * e; }
+    else if (base == "f") { *offset_bytes = L.f[l]; *size_bytes = R * (size_t)h->cfg.ffn * e; }
+    else if (base == "h2") { *offset_bytes = L.h2[l]; *size_bytes = R * d * e; }
+    else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
+    else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
+    else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }
+    else if (train && base == "dP") { *offset_bytes = L.dP; *size_bytes = R * d * e; }
+    else if (train && base == "dM") { *offset_bytes = L.dM; *size_bytes = R * d * e; }
+    else if (train && base == "dO") { *offset_bytes = L.dO; *size_bytes = R * d * e; }
+    else if (train && base == "dQKV") { *offset_bytes = L.dQKV; *size_bytes = R * 3 * d * e; }
+    else return GE2E_EINVAL;
+    return 0;
+}
+
+uint32_t ge2e_drop_key(uint64_t seed, uint64_t step, int site) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + step * 0xBF58476D1CE4E5B9ull + (uint64_t)(site + 1) * 0x94D049BB133111EBull;
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27; z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z & 0xFFFFFFFFull);
+}
+
+int ge2e_drop_keep(uint32_t key, uint32_t index, float p) {
+    const uint32_t thr = (uint32_t)std::floor((double)p * 16777216.0);
+    return drop_keep(index, key, thr) ? 1 : 0;
+}
+
+}  // extern "C"

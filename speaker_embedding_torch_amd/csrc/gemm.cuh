@@ -1,0 +1,368 @@
+// Projection GEMMs of the GE2E encoder (SURVEY.md 8a rows a1, a3, a5, a6 and their backward a13).
+//
+//   gemm_nt_kernel : C[M,N] = A[M,K] * W[N,K]^T  (+ fused epilogue)   -- forward and dgrad
+//   wgrad_kernel   : dW[N,K] += Y[R,N]^T * X[R,K], db[N] += colsum(Y) -- weight gradients (split over R)
+//
+// Both run on MFMA 16x16 tiles in either arithmetic mode (common.cuh).  A block owns a BM x BN
+// output tile; operands are staged global -> registers -> LDS (register-staged double buffer:
+// loads for k-step s+1 are issued before the MFMAs of step s and written to LDS after them).
+#pragma once
+#include "common.cuh"
+
+namespace ge2e {
+
+enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD };
+enum { ALOAD_ROW = 0, ALOAD_MEL };
+
+struct GemmArgs {
+    const void* A; int lda;      // [M, K] of T (ALOAD_ROW)  |  mel fp32 [n, mel, T] (ALOAD_MEL)
+    const void* W; int ldw;      // [N, K] of T
+    void* C; int ldc;            // [M, N] of T
+    int M, N, K;                 // K = padded reduction length (multiple of 128 / sizeof(T))
+    const float* bias;           // [N]
+    const void* R; int ldr;      // residual (EPI_LN), addend (EPI_ADD), mask source (EPI_MASK), dH0 (EPI_PRENET_BWD)
+    const float* gamma; const float* beta; float* rstd; float eps;   // EPI_LN
+    Drop drop;                   // dropout site of this epilogue (thr == 0: inactive)
+    float mask_scale;            // EPI_MASK: gradient scale of kept elements
+    const float* pe_t;           // [T, N] transposed positional table (prenet)
+    const float* alpha;          // positional_encoding.alpha (device scalar)
+    float* dalpha;               // EPI_PRENET_BWD: scalar accumulator
+    int T, mel;                  // frames per utterance, real mel dim (ALOAD_MEL / prenet epilogues)
+};
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD>
+__global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
+    constexpr int FRAG = Prec<T>::FRAG;
+    constexpr int BK = 128 / (int)sizeof(T);            // 128-byte LDS rows = two k-groups
+    constexpr int WAVES_N = BN / WN;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int NA = BM / 32, NB = BN / 32;            // 16-byte chunks per thread and stage
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves");
+    static_assert(ALOAD == ALOAD_ROW || BM == 128, "mel loader assumes 128 rows");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;                       // [2][BM][128 B]
+    unsigned char* const Bs = smem + 2 * BM * 128;        // [2][BN][128 B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int nbn = p.N / BN;
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (L / nbn) * BM, n0 = (L % nbn) * BN;
+    const int nk = p.K / BK;
+
+    u32x4 ra[NA], rb[NB];
+    auto load_stage = [&](int ks) {
+        const int k0 = ks * BK;
+        if constexpr (ALOAD == ALOAD_ROW) {
+            const unsigned char* A = (const unsigned char*)p.A;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int id = tid + 256 * q, row = id >> 3, c = id & 7, gr = m0 + row;
+                ra[q] = gr < p.M ? *(const u32x4*)(A + ((size_t)gr * p.lda + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+            }
+        } else {
+            // A[r][k] = mel[n][k][t], r = n*T + t: lanes run along t (contiguous in memory)
+            const float* X = (const float*)p.A;
+            const int row = tid & 127, gr = m0 + row;
+            const int n = gr / p.T, t = gr - n * p.T;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int c = (tid >> 7) + 2 * q;
+                float v[FRAG];
+#pragma unroll
+                for (int j = 0; j < FRAG; ++j) {
+                    const int k = k0 + c * FRAG + j;
+                    v[j] = (gr < p.M && k < p.mel) ? X[((size_t)n * p.mel + k) * p.T + t] : 0.0f;
+                }
+                if constexpr (sizeof(T) == 4) ra[q] = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                else ra[q] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4 % FRAG], v[5 % FRAG]), pack_bf16x2(v[6 % FRAG], v[7 % FRAG])};
+            }
+        }
+        const unsigned char* W = (const unsigned char*)p.W;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int id = tid + 256 * q, row = id >> 3, c = id & 7, gr = n0 + row;
+            rb[q] = gr < p.N ? *(const u32x4*)(W + ((size_t)gr * p.ldw + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+        }
+    };
+    auto store_stage = [&](int buf) {
+        unsigned char* a = As + buf * BM * 128;
+        unsigned char* b = Bs + buf * BN * 128;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            int row, c;
+            if constexpr (ALOAD == ALOAD_ROW) { const int id = tid + 256 * q; row = id >> 3; c = id & 7; }
+            else { row = tid & 127; c = (tid >> 7) + 2 * q; }
+            *(u32x4*)(a + swz_off<128>(row, c)) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int id = tid + 256 * q;
+            *(u32x4*)(b + swz_off<128>(id >> 3, id & 7)) = rb[q];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_stage(ks + 1);
+        const unsigned char* a = As + buf * BM * 128;
+        const unsigned char* b = Bs + buf * BN * 128;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            u32x4 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = lds16(a + swz_off<128>(wm * WM + mt * 16 + i, kg * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 bf = lds16(b + swz_off<128>(wn * WN + nt * 16 + i, kg * 4 + g));
+                // operand order (W rows as MFMA "A", activation rows as MFMA "B") puts an activation row on a
+                // lane: acc[mt][nt][r] = C[m0 + wm*WM + mt*16 + i][n0 + wn*WN + nt*16 + 4g + r]
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mma16<T>(bf, af[mt], acc[mt][nt]);
+            }
+        }
+        if (ks + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    T* const C = (T*)p.C;
+    const T* const Rm = (const T*)p.R;
+    float dal = 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = m0 + wm * WM + mt * 16 + i;
+        const bool ok = row < p.M;
+        const int colb = n0 + wn * WN + 4 * g;
+        if constexpr (EPI == EPI_LN) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = colb + nt * 16;
+                const f32x4 b4 = *(const f32x4*)(p.bias + col);
+                f32x4 r4 = f32x4{0, 0, 0, 0};
+                if (ok) r4 = load4(Rm + (size_t)row * p.ldr + col);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mt][nt][r] + b4[r];
+                    v = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), v) + r4[r];
+                    acc[mt][nt][r] = v;
+                    sum += v;
+                }
+            }
+            const float mean = cross4_sum(sum) * (1.0f / (float)BN);
+            float sq = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = acc[mt][nt][r] - mean; sq += d * d; }
+            const float rstd = 1.0f / sqrtf(cross4_sum(sq) * (1.0f / (float)BN) + p.eps);
+            if (ok) {
+                if (g == 0 && p.rstd) p.rstd[row] = rstd;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = colb + nt * 16;
+                    const f32x4 g4 = *(const f32x4*)(p.gamma + col), be4 = *(const f32x4*)(p.beta + col);
+                    store4(C + (size_t)row * p.ldc + col,
+                           (acc[mt][nt][0] - mean) * rstd * g4[0] + be4[0], (acc[mt][nt][1] - mean) * rstd * g4[1] + be4[1],
+                           (acc[mt][nt][2] - mean) * rstd * g4[2] + be4[2], (acc[mt][nt][3] - mean) * rstd * g4[3] + be4[3]);
+                }
+            }
+        } else {
+            int t = 0;
+            if constexpr (EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) t = row % p.T;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = colb + nt * 16;
+                f32x4 v = acc[mt][nt];
+                if (!ok) continue;
+                if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) {
+                    const f32x4 b4 = *(const f32x4*)(p.bias + col);
+                    v += b4;
+                }
+                if constexpr (EPI == EPI_BIAS_RELU_DROP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), fmaxf(v[r], 0.0f));
+                }
+                if constexpr (EPI == EPI_PRENET) {
+                    const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
+                    const float al = *p.alpha;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v[r] = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), fmaxf(v[r], 0.0f) + al * pe4[r]);
+                }
+                if constexpr (EPI == EPI_PRENET_BWD) {
+                    // v = prenet pre-activation (recomputed); R = dL/dh0 -> masked gradient of the pre-activation
+                    const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
+                    const f32x4 d4 = load4(Rm + (size_t)row * p.ldr + col);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gv = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), d4[r]);
+                        dal += gv * pe4[r];
+                        v[r] = v[r] > 0.0f ? gv : 0.0f;
+                    }
+                }
+                if constexpr (EPI == EPI_MASK) {
+                    const f32x4 m4 = load4(Rm + (size_t)row * p.ldr + col);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
+                }
+                if constexpr (EPI == EPI_ADD) v += load4(Rm + (size_t)row * p.ldr + col);
+                store4(C + (size_t)row * p.ldc + col, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if constexpr (EPI == EPI_PRENET_BWD) {
+        float* red = (float*)smem;      // main loop ended with a barrier; LDS is free
+        const float s = block256_sum(dal, red);
+        if (tid == 0) atomicAdd(p.dalpha, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient: dW[n][k] += sum_r Y[r][n] * X[r][k] over this block's slice of rows.
+// Both operands are read TRANSPOSED from plain padded LDS tiles ([row][128 cols]).
+// XLOAD_MEL: X[r][k] = mel[n][k][t] (prenet), k < mel, zero beyond.
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const void* Y; int ldy;     // [R, N] of T
+    const void* X; int ldx;     // [R, K] of T   |  mel fp32
+    float* dW; int ldw;         // [N, ldw] fp32 accumulate (atomics)
+    float* db;                  // [N] or null
+    int R, N, K;                // K = real width (dW columns written: k < K)
+    int rows_per_split;         // multiple of the stage height
+    int T, mel;
+};
+
+template <typename T, int XLOAD>
+__global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
+    constexpr int KG = Prec<T>::KG;
+    constexpr int RS = 2 * KG;                              // rows per stage
+    constexpr int ROWB = 128 * (int)sizeof(T);              // 128 columns
+    constexpr int LD = ROWB + 16;
+    constexpr int CPR = ROWB / 16;                          // chunks per row
+    constexpr int NCH = RS * CPR / 256;                     // chunks per thread (= 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Ys = smem;                         // [2][RS][LD]
+    unsigned char* const Xs = smem + 2 * RS * LD;           // [2][RS][LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int rbeg = blockIdx.z * p.rows_per_split;
+    const int rend = min(p.R, rbeg + p.rows_per_split);
+    const int nst = (rend - rbeg + RS - 1) / RS;
+
+    if constexpr (XLOAD == ALOAD_MEL) {     // columns >= mel are never written by the loader: zero once
+        for (int q = tid; q < 2 * RS * LD / 16; q += 256) *(u32x4*)(Xs + q * 16) = u32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+
+    u32x4 ry[NCH], rx[NCH];
+    auto load_stage = [&](int st) {
+        const int r0 = rbeg + st * RS;
+        const unsigned char* Y = (const unsigned char*)p.Y;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
+            ry[q] = gr < rend ? *(const u32x4*)(Y + ((size_t)gr * p.ldy + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+        }
+        if constexpr (XLOAD == ALOAD_ROW) {
+            const unsigned char* X = (const unsigned char*)p.X;
+#pragma unroll
+            for (int q = 0; q < NCH; ++q) {
+                const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
+                rx[q] = gr < rend ? *(const u32x4*)(X + ((size_t)gr * p.ldx + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    auto store_stage = [&](int buf, int st) {
+        unsigned char* y = Ys + buf * RS * LD;
+        unsigned char* x = Xs + buf * RS * LD;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int id = tid + 256 * q, row = id / CPR, c = id % CPR;
+            *(u32x4*)(y + row * LD + c * 16) = ry[q];
+            if constexpr (XLOAD == ALOAD_ROW) *(u32x4*)(x + row * LD + c * 16) = rx[q];
+        }
+        if constexpr (XLOAD == ALOAD_MEL) {   // small operand (mel <= 128 columns): global -> LDS directly, lanes along t
+            const float* X = (const float*)p.X;
+            const int r0 = rbeg + st * RS;
+            for (int id = tid; id < RS * p.mel; id += 256) {
+                const int row = id % RS, m = id / RS, gr = r0 + row;
+                const int n = gr / p.T, t = gr - n * p.T;
+                const float v = gr < rend ? X[((size_t)n * p.mel + m) * p.T + t] : 0.0f;
+                *(T*)(x + row * LD + m * sizeof(T)) = from_f32<T>(v);
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
+    float bsum = 0.0f;
+    const bool do_bias = (p.db != nullptr) && blockIdx.y == 0;
+
+    if (nst > 0) {
+        load_stage(0);
+        store_stage(0, 0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const unsigned char* y = Ys + buf * RS * LD;
+        const unsigned char* x = Xs + buf * RS * LD;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            u32x4 af[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) af[mt] = frag_tr<T>(y, LD, kg * KG, wm * 64 + mt * 16, lane);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const u32x4 bf = frag_tr<T>(x, LD, kg * KG, wn * 64 + nt * 16, lane);
+                // acc[mt][nt][r] = dW[n0 + wm*64 + mt*16 + 4g + r][k0 + wn*64 + nt*16 + i]
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mma16<T>(af[mt], bf, acc[mt][nt]);
+            }
+        }
+        if (do_bias) {
+            const int col = tid & 127, half = tid >> 7;
+#pragma unroll 4
+            for (int r = half * (RS / 2); r < (half + 1) * (RS / 2); ++r) bsum += to_f32(*(const T*)(y + r * LD + col * sizeof(T)));
+        }
+        if (st + 1 < nst) store_stage(buf ^ 1, st + 1);
+        __syncthreads();
+    }
+    if (nst == 0) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int k = k0 + wn * 64 + nt * 16 + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wm * 64 + mt * 16 + 4 * g + r;
+                if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[mt][nt][r]);
+            }
+        }
+    if (do_bias) {
+        const int col = tid & 127;
+        if (n0 + col < p.N) atomicAdd(p.db + n0 + col, bsum);
+    }
+}
+
+}  // namespace ge2e

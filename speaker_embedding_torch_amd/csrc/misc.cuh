@@ -1,0 +1,304 @@
+// Bandwidth-bound pieces of the GE2E hot path: weight preparation, LayerNorm backward, the t=0 tail
+// (final LN -> slice mean -> projection -> L2 norm) and the GE2E loss
+// (rows a10-a12), each with its backward.  Rows are D = 256 wide: a wave holds a row as 4 floats/lane.
+#pragma once
+#include "common.cuh"
+
+namespace ge2e {
+
+// ---------------------------------------------------------------------------------------------
+// weight preparation: fp32 master [rows][cols] -> T [rows][ldd] (zero padded) and T^T [cols][rows]
+// ---------------------------------------------------------------------------------------------
+struct PrepJob {
+    const float* src; void* dst; void* dstT;
+    int rows, cols, ldd;        // ldd >= cols
+    int tile0;                  // first 32x32 tile index of this job
+    int tiles_x;                // tiles along the (padded) column dim
+};
+constexpr int PREP_MAX_JOBS = 16;
+struct PrepArgs { PrepJob job[PREP_MAX_JOBS]; int njobs; };
+
+template <typename T>
+__global__ void __launch_bounds__(256) prep_weights_kernel(const PrepArgs a) {
+    __shared__ float tile[32][33];
+    int j = 0;
+#pragma unroll 1
+    for (int q = 1; q < a.njobs; ++q) if ((int)blockIdx.x >= a.job[q].tile0) j = q;
+    const PrepJob jb = a.job[j];
+    const int tl = blockIdx.x - jb.tile0, ty = tl / jb.tiles_x, tx = tl % jb.tiles_x;
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ly; r < 32; r += 8) {
+        const int row = ty * 32 + r, col = tx * 32 + lx;
+        const float v = (row < jb.rows && col < jb.cols) ? jb.src[(size_t)row * jb.cols + col] : 0.0f;
+        tile[r][lx] = v;
+        if (row < jb.rows && col < jb.ldd) ((T*)jb.dst)[(size_t)row * jb.ldd + col] = from_f32<T>(v);
+    }
+    __syncthreads();
+    if (jb.dstT) {
+#pragma unroll
+        for (int r = ly; r < 32; r += 8) {
+            const int col = tx * 32 + r, row = ty * 32 + lx;     // dstT[col][row]
+            if (row < jb.rows && col < jb.cols) ((T*)jb.dstT)[(size_t)col * jb.rows + row] = from_f32<T>(tile[lx][r]);
+        }
+    }
+}
+
+// fp32 [rows][cols] -> fp32 transposed [take][rows]: pe buffer [D][max_pos] -> pe_t [T][D]; Wq -> Wq^T
+__global__ void __launch_bounds__(256) transpose_f32_kernel(const float* src, float* dst, int rows, int cols, int take) {
+    __shared__ float tile[32][33];
+    const int tx = blockIdx.x, ty = blockIdx.y, lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    for (int r = ly; r < 32; r += 8) {
+        const int row = ty * 32 + r, col = tx * 32 + lx;
+        tile[r][lx] = (row < rows && col < cols) ? src[(size_t)row * cols + col] : 0.0f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+        const int col = tx * 32 + r, row = ty * 32 + lx;
+        if (row < rows && col < take) dst[(size_t)col * rows + row] = tile[lx][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward over rows of 256 (post-LN residual blocks).  xhat is rebuilt from the saved
+// OUTPUT y: xhat = (y - beta) / gamma (gamma == 0 columns carry no xhat information: treated as 0).
+// ---------------------------------------------------------------------------------------------
+struct LnBwdArgs {
+    const void* dy; const void* y;
+    const float* gamma; const float* beta; const float* rstd;
+    void* dpre;          // gradient wrt the LN input (residual path)
+    void* dmask;         // same, through the dropout in front of the sub-layer (null: not needed)
+    float* dgamma; float* dbeta;
+    int R;
+    Drop drop;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
+    __shared__ float red[2][4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = lane * 4;
+    const f32x4 ga = *(const f32x4*)(p.gamma + c0), be = *(const f32x4*)(p.beta + c0);
+    f32x4 ig;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ig[r] = ga[r] != 0.0f ? 1.0f / ga[r] : 0.0f;
+    f32x4 ag = f32x4{0, 0, 0, 0}, ab = f32x4{0, 0, 0, 0};
+    for (int row = blockIdx.x * 4 + wave; row < p.R; row += gridDim.x * 4) {
+        const f32x4 dy = load4((const T*)p.dy + (size_t)row * 256 + c0);
+        const f32x4 y = load4((const T*)p.y + (size_t)row * 256 + c0);
+        const float rs = p.rstd[row];
+        f32x4 xh, dxh;
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xh[r] = (y[r] - be[r]) * ig[r];
+            dxh[r] = dy[r] * ga[r];
+            s1 += dxh[r];
+            s2 += dxh[r] * xh[r];
+            ag[r] += dy[r] * xh[r];
+            ab[r] += dy[r];
+        }
+        s1 = wave_sum(s1) * (1.0f / 256.0f);
+        s2 = wave_sum(s2) * (1.0f / 256.0f);
+        f32x4 dx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dx[r] = rs * (dxh[r] - s1 - xh[r] * s2);
+        store4((T*)p.dpre + (size_t)row * 256 + c0, dx[0], dx[1], dx[2], dx[3]);
+        if (p.dmask) {
+            const uint32_t ib = (uint32_t)row * 256u + (uint32_t)c0;
+            store4((T*)p.dmask + (size_t)row * 256 + c0, drop_apply(p.drop, ib, dx[0]), drop_apply(p.drop, ib + 1, dx[1]),
+                   drop_apply(p.drop, ib + 2, dx[2]), drop_apply(p.drop, ib + 3, dx[3]));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[0][wave][c0 + r] = ag[r]; red[1][wave][c0 + r] = ab[r]; }
+    __syncthreads();
+    const int c = threadIdx.x;
+    atomicAdd(p.dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(p.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// tail: z = LN_f(h[n, t=0, :]); z' = mean over `samples`; e = Wq z' + bq; e /= max(|e|, 1e-12)
+// fp32 arithmetic in both modes (0.13 MFLOP/utt).  One block of 256 threads per output embedding.
+// ---------------------------------------------------------------------------------------------
+struct TailArgs {
+    const void* h;               // [N*T, 256] of T (last layer output)
+    int T, samples, N;           // N = utterances (rows used: n*T)
+    const float* gf; const float* bf;      // transformer.norm
+    const float* wq; const float* wqT; const float* bq;   // projection [256][256], its transpose, bias
+    float eps;
+    float* xhat; float* rstd;    // [N,256], [N]   saved for backward
+    float* zm; float* nrm;       // [N/samples,256], [N/samples]
+    float* emb;                  // [N/samples,256] output (also kept for backward)
+    // backward
+    const float* d_emb; float* d_raw; void* dH;      // dH: [N*T,256] of T, only rows t=0 written
+    float* dgf; float* dbf; float* dwq; float* dbq;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) tail_fwd_kernel(const TailArgs p) {
+    __shared__ float red[4];
+    __shared__ float zs[256];
+    const int m = blockIdx.x, c = threadIdx.x;
+    float zsum = 0.0f;
+    for (int s = 0; s < p.samples; ++s) {
+        const int row = m * p.samples + s;
+        const float v = to_f32(((const T*)p.h)[(size_t)row * p.T * 256 + c]);
+        const float mean = block256_sum(v, red) * (1.0f / 256.0f);
+        const float d = v - mean;
+        const float rs = 1.0f / sqrtf(block256_sum(d * d, red) * (1.0f / 256.0f) + p.eps);
+        const float xh = d * rs;
+        if (p.xhat) { p.xhat[(size_t)row * 256 + c] = xh; if (c == 0) p.rstd[row] = rs; }
+        zsum += xh * p.gf[c] + p.bf[c];
+    }
+    const float z = zsum / (float)p.samples;
+    if (p.zm) p.zm[(size_t)m * 256 + c] = z;
+    zs[c] = z;
+    __syncthreads();
+    float e = p.bq[c];
+#pragma unroll 8
+    for (int k = 0; k < 256; ++k) e += zs[k] * p.wqT[k * 256 + c];
+    const float nn = fmaxf(sqrtf(block256_sum(e * e, red)), 1e-12f);
+    p.emb[(size_t)m * 256 + c] = e / nn;
+    if (c == 0 && p.nrm) p.nrm[m] = nn;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) tail_bwd_kernel(const TailArgs p) {
+    __shared__ float red[4];
+    __shared__ float dr[256];
+    const int m = blockIdx.x, c = threadIdx.x;
+    const float de = p.d_emb[(size_t)m * 256 + c], e = p.emb[(size_t)m * 256 + c];
+    const float dot = block256_sum(de * e, red);
+    const float draw = (de - e * dot) / p.nrm[m];
+    p.d_raw[(size_t)m * 256 + c] = draw;
+    dr[c] = draw;
+    __syncthreads();
+    float dzm = 0.0f;
+#pragma unroll 8
+    for (int j = 0; j < 256; ++j) dzm += dr[j] * p.wq[j * 256 + c];
+    const float dz = dzm / (float)p.samples;
+    const float g = p.gf[c];
+    float ag = 0.0f;
+    for (int s = 0; s < p.samples; ++s) {
+        const int row = m * p.samples + s;
+        const float xh = p.xhat[(size_t)row * 256 + c];
+        const float dxh = dz * g;
+        const float m1 = block256_sum(dxh, red) * (1.0f / 256.0f);
+        const float m2 = block256_sum(dxh * xh, red) * (1.0f / 256.0f);
+        ((T*)p.dH)[(size_t)row * p.T * 256 + c] = from_f32<T>(p.rstd[row] * (dxh - m1 - xh * m2));
+        ag += dz * xh;
+    }
+    atomicAdd(p.dgf + c, ag);
+    atomicAdd(p.dbf + c, dz * (float)p.samples);
+}
+
+// dWq[c][k] = sum_m d_raw[m][c] * zm[m][k]; dbq[c] = sum_m d_raw[m][c].  grid = 256 (row c), deterministic.
+__global__ void __launch_bounds__(256) tail_wgrad_kernel(const TailArgs p) {
+    const int c = blockIdx.x, k = threadIdx.x, M = p.N / p.samples;
+    float acc = 0.0f, bsum = 0.0f;
+    for (int m = 0; m < M; ++m) {
+        const float d = p.d_raw[(size_t)m * 256 + c];
+        acc += d * p.zm[(size_t)m * 256 + k];
+        bsum += d;
+    }
+    p.dwq[c * 256 + k] = acc;
+    if (k == 0) p.dbq[c] = bsum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GE2E loss (reference Modules.py:121-156).  fp32, D = 256.
+//   workspace (floats): cent[S*256] cn[S] en[N] rowloss[N] G[N*S] cosm[N*S] dC[S*256]
+// ---------------------------------------------------------------------------------------------
+struct LossArgs {
+    const float* emb; int N, S, P;
+    float w, b;
+    float* cent; float* cn; float* en; float* rowloss; float* G; float* cosm; float* dC;
+    float* loss;                 // [1]
+    const float* gscale;         // device scalar dL/dloss (backward)
+    float* d_emb;                // [N,256]
+};
+
+__global__ void __launch_bounds__(256) loss_centroid_kernel(const LossArgs p) {
+    __shared__ float red[4];
+    const int s = blockIdx.x, c = threadIdx.x;
+    float acc = 0.0f;
+    for (int q = 0; q < p.P; ++q) acc += p.emb[((size_t)s * p.P + q) * 256 + c];
+    acc /= (float)p.P;
+    p.cent[(size_t)s * 256 + c] = acc;
+    const float nn = fmaxf(sqrtf(block256_sum(acc * acc, red)), 1e-8f);
+    if (c == 0) p.cn[s] = nn;
+}
+
+__global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* sims = (float*)smem;             // [S]
+    float* coss = sims + p.S;               // [S]
+    __shared__ float bc[2];
+    const int irow = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4 e = *(const f32x4*)(p.emb + (size_t)irow * 256 + lane * 4);
+    const float en = fmaxf(sqrtf(wave_sum(e[0] * e[0] + e[1] * e[1] + e[2] * e[2] + e[3] * e[3])), 1e-8f);
+    for (int s = wave; s < p.S; s += 4) {
+        const f32x4 cv = *(const f32x4*)(p.cent + (size_t)s * 256 + lane * 4);
+        const float dot = wave_sum(e[0] * cv[0] + e[1] * cv[1] + e[2] * cv[2] + e[3] * cv[3]);
+        const float cs = dot / (en * p.cn[s]);
+        if (lane == 0) { coss[s] = cs; sims[s] = p.w * cs - p.b; }
+    }
+    __syncthreads();
+    const int own = irow / p.P;
+    if (wave == 0) {
+        float mx = -INFINITY;
+        for (int s = lane; s < p.S; s += 64) mx = fmaxf(mx, sims[s]);
+        mx = wave_max(mx);
+        float sum = 0.0f;
+        for (int s = lane; s < p.S; s += 64) sum += expf(sims[s] - mx);
+        sum = wave_sum(sum);
+        const float lse = mx + logf(sum);
+        if (lane == 0) { bc[0] = lse; p.rowloss[irow] = lse - sims[own]; p.en[irow] = en; }
+    }
+    __syncthreads();
+    const float lse = bc[0];
+    const float k = p.w / (float)p.N;
+    for (int s = threadIdx.x; s < p.S; s += 256) {
+        p.G[(size_t)irow * p.S + s] = (expf(sims[s] - lse) - (s == own ? 1.0f : 0.0f)) * k;
+        p.cosm[(size_t)irow * p.S + s] = coss[s];
+    }
+}
+
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const LossArgs p) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int q = threadIdx.x; q < p.N; q += 256) acc += p.rowloss[q];
+    const float t = block256_sum(acc, red);
+    if (threadIdx.x == 0) p.loss[0] = t / (float)p.N;
+}
+
+// dC[s][c] = (sum_i G[i][s] ehat_i[c]) / cn_s - (sum_i G[i][s] cos[i][s]) c_s[c] / cn_s^2
+__global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    float a = 0.0f, gc = 0.0f;
+    for (int q = 0; q < p.N; ++q) {
+        const float g = p.G[(size_t)q * p.S + s];
+        a += g * p.emb[(size_t)q * 256 + c] / p.en[q];
+        gc += g * p.cosm[(size_t)q * p.S + s];
+    }
+    const float cn = p.cn[s];
+    p.dC[(size_t)s * 256 + c] = a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn);
+}
+
+// d_emb_i = gscale * ( (G_i chat)/en_i - (G_i . cos_i) e_i / en_i^2 + dC[spk(i)] / P )
+__global__ void __launch_bounds__(256) loss_bwd_row_kernel(const LossArgs p) {
+    const int irow = blockIdx.x, c = threadIdx.x;
+    float a = 0.0f, gc = 0.0f;
+    for (int s = 0; s < p.S; ++s) {
+        const float g = p.G[(size_t)irow * p.S + s];
+        a += g * p.cent[(size_t)s * 256 + c] / p.cn[s];
+        gc += g * p.cosm[(size_t)irow * p.S + s];
+    }
+    const float en = p.en[irow];
+    const float v = a / en - gc * p.emb[(size_t)irow * 256 + c] / (en * en) + p.dC[(size_t)(irow / p.P) * 256 + c] / (float)p.P;
+    p.d_emb[(size_t)irow * 256 + c] = v * p.gscale[0];
+}
+
+}  // namespace ge2e
