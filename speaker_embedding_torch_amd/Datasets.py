@@ -1,0 +1,90 @@
+"""Host-side batch assembly over the reference's on-disk pattern format (behaviour of reference Datasets.py:9-109).
+
+Pattern file: pickle {'Mel': float16[Mel_dim, T_full], 'Speaker': str, 'Dataset': str} as written by the
+reference's Pattern_Generator.py:191-198; METADATA.PICKLE carries 'File_List_by_Speaker_Dict'.  Only files
+that this project's users generated themselves are unpickled.  A training batch is float32
+[Speakers * Pattern_per_Speaker, Mel, T], speaker-major, with ONE random T per batch; an inference batch
+stacks `samples` overlapping windows per utterance.  The mel stays fp16 on disk and is widened once here.
+"""
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+
+def Correction(feature, frame_length):
+    """Bring a [Mel, T_full] pattern to exactly frame_length frames: random crop when longer, symmetric
+    reflect padding (floor/ceil split) when shorter -- Datasets.py:9-19."""
+    surplus = feature.shape[1] - frame_length
+    if surplus > 0:
+        start = np.random.randint(0, surplus)
+        return feature[:, start:start + frame_length]
+    left = (-surplus) // 2
+    return np.pad(feature, ((0, 0), (left, -surplus - left)), mode="reflect")
+
+
+def _load_pickle(path):
+    with open(path.replace("\\", "/"), "rb") as handle:
+        return pickle.load(handle)
+
+
+def _to_batch(list_of_arrays):
+    return torch.from_numpy(np.ascontiguousarray(np.stack(list_of_arrays, axis=0), dtype=np.float32))
+
+
+class Dataset(torch.utils.data.Dataset):
+    """Index = speaker; item = `pattern_per_speaker` randomly drawn (mel, speaker) pairs (Datasets.py:22-69).
+    Speakers with fewer files than that are dropped; `num_speakers` optionally subsamples the speaker set."""
+
+    def __init__(self, pattern_path, metadata_file, pattern_per_speaker, num_speakers=None):
+        self.pattern_path = pattern_path
+        self.pattern_per_speaker = pattern_per_speaker
+        table = _load_pickle(os.path.join(pattern_path, metadata_file))["File_List_by_Speaker_Dict"]
+        usable = {spk: files for spk, files in table.items() if len(files) >= pattern_per_speaker}
+        if num_speakers is not None and num_speakers < len(usable):
+            usable = {spk: usable[spk] for spk in random.sample(list(usable), num_speakers)}
+        self.files_by_speakers = usable
+        self.speakers = list(usable)
+
+    def __len__(self):
+        return len(self.speakers)
+
+    def __getitem__(self, idx):
+        speaker = self.speakers[idx]
+        chosen = random.sample(self.files_by_speakers[speaker], self.pattern_per_speaker)
+        return [(_load_pickle(os.path.join(self.pattern_path, name))["Mel"], speaker) for name in chosen]
+
+
+class Collater:
+    """Train/eval collate_fn (Datasets.py:72-86)."""
+
+    def __init__(self, min_frame_length, max_frame_length):
+        self.min_frame_length, self.max_frame_length = min_frame_length, max_frame_length
+
+    def __call__(self, batch):
+        frames = np.random.randint(self.min_frame_length, self.max_frame_length + 1)
+        return _to_batch([Correction(mel, frames) for item in batch for mel, _ in item])
+
+
+class Inference_Collater:
+    """`samples` windows of `frame_length` with hop frame_length - overlap_length per utterance, stacked to
+    [Speakers * Samples, Mel_dim, Time]; returns (features, speaker labels) -- Datasets.py:88-109."""
+
+    def __init__(self, samples, frame_length, overlap_length):
+        self.samples, self.frame_length, self.overlap_length = samples, frame_length, overlap_length
+        self.required_length = samples * (frame_length - overlap_length) + overlap_length
+
+    def slices(self, feature):
+        feature = Correction(feature, self.required_length)
+        hop = self.frame_length - self.overlap_length
+        return [feature[:, s:s + self.frame_length] for s in range(0, self.required_length - self.overlap_length, hop)]
+
+    def __call__(self, batch):
+        windows, speakers = [], []
+        for item in batch:
+            for mel, speaker in item:
+                windows.extend(self.slices(mel))
+                speakers.append(speaker)
+        return _to_batch(windows), speakers

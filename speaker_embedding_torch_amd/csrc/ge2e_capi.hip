@@ -400,7 +400,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dwq = G(p_proj_w(c)); a.dbq = G(p_proj_b(c));
         auto kern = tail_bwd_kernel<T>;
         GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
-        GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d), dim3(256), 0, st, a);
+        GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, st, a);
         bucket(p_fn_w(c), p_proj_b(c));
     }
     const int ln_grid = std::min(2048, (R + 3) / 4);
@@ -640,7 +640,9 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     hipStream_t st = (hipStream_t)stream;
     LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
     a.gscale = d_loss; a.d_emb = d_emb;
-    GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers), dim3(256), 0, st, a);
+    hipError_t em = hipMemsetAsync(a.dC, 0, (size_t)speakers * h->cfg.emb * 4, st);
+    if (em != hipSuccess) return fail_hip(h, em, "zero dC");
+    GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers, std::max(1, std::min(32, (a.N + 31) / 32))), dim3(256), 0, st, a);
     GE2E_LAUNCH(h, loss_bwd_row_kernel, dim3(a.N), dim3(256), 0, st, a);
     return 0;
 }

@@ -194,17 +194,20 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const TailArgs p) {
     atomicAdd(p.dbf + c, dz * (float)p.samples);
 }
 
-// dWq[c][k] = sum_m d_raw[m][c] * zm[m][k]; dbq[c] = sum_m d_raw[m][c].  grid = 256 (row c), deterministic.
+// dWq[c][k] += sum_m d_raw[m][c] * zm[m][k]; dbq[c] += sum_m d_raw[m][c].  grid = (256 rows c, m-slices);
+// the gradient buffer is zeroed at the start of backward, slices combine with one atomic per element.
 __global__ void __launch_bounds__(256) tail_wgrad_kernel(const TailArgs p) {
     const int c = blockIdx.x, k = threadIdx.x, M = p.N / p.samples;
+    const int per = (M + gridDim.y - 1) / gridDim.y, m0 = blockIdx.y * per, m1 = min(M, m0 + per);
     float acc = 0.0f, bsum = 0.0f;
-    for (int m = 0; m < M; ++m) {
+#pragma unroll 4
+    for (int m = m0; m < m1; ++m) {
         const float d = p.d_raw[(size_t)m * 256 + c];
         acc += d * p.zm[(size_t)m * 256 + k];
         bsum += d;
     }
-    p.dwq[c * 256 + k] = acc;
-    if (k == 0) p.dbq[c] = bsum;
+    atomicAdd(p.dwq + c * 256 + k, acc);
+    if (k == 0) atomicAdd(p.dbq + c, bsum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -274,17 +277,20 @@ __global__ void __launch_bounds__(256) loss_reduce_kernel(const LossArgs p) {
     if (threadIdx.x == 0) p.loss[0] = t / (float)p.N;
 }
 
-// dC[s][c] = (sum_i G[i][s] ehat_i[c]) / cn_s - (sum_i G[i][s] cos[i][s]) c_s[c] / cn_s^2
+// dC[s][c] += (sum_i G[i][s] ehat_i[c]) / cn_s - (sum_i G[i][s] cos[i][s]) c_s[c] / cn_s^2 over this block's slice
+// of utterances (the expression is linear in the two sums, so slices combine by atomics on a zeroed dC).
 __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p) {
     const int s = blockIdx.x, c = threadIdx.x;
+    const int per = (p.N + gridDim.y - 1) / gridDim.y, q0 = blockIdx.y * per, q1 = min(p.N, q0 + per);
     float a = 0.0f, gc = 0.0f;
-    for (int q = 0; q < p.N; ++q) {
+#pragma unroll 4
+    for (int q = q0; q < q1; ++q) {
         const float g = p.G[(size_t)q * p.S + s];
         a += g * p.emb[(size_t)q * 256 + c] / p.en[q];
         gc += g * p.cosm[(size_t)q * p.S + s];
     }
     const float cn = p.cn[s];
-    p.dC[(size_t)s * 256 + c] = a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn);
+    atomicAdd(p.dC + (size_t)s * 256 + c, a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn));
 }
 
 // d_emb_i = gscale * ( (G_i chat)/en_i - (G_i . cos_i) e_i / en_i^2 + dC[spk(i)] / P )

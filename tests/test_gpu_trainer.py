@@ -1,0 +1,164 @@
+"""GPU tests of the Train.py / Inference.py shaped glue: the Train_Step order (forward -> loss -> backward ->
+clip -> AdamW) pinned against the reference's own numbers (golden G4), checkpoints with the reference key set,
+multi-slice inference from a saved checkpoint, and 2-rank data parallelism with real HIP backward kernels."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from oracle import ge2e_oracle as O
+from conftest import rel_l2
+from test_host_glue import make_patterns
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml")
+
+
+def write_hp(tmp_path, **over):
+    hp = yaml.safe_load(open(HP))
+    hp["Checkpoint_Path"] = str(tmp_path / "ckpt")
+    hp["Log_Path"] = str(tmp_path / "log")
+    hp["Use_Mixed_Precision"] = over.pop("bf16", False)
+    p = over.pop("dropout", 0.1)
+    hp["GE2E"]["Positional_Encoding"]["Dropout_Rate"] = p
+    hp["GE2E"]["Transformer"]["Dropout_Rate"] = p
+    for k, v in over.items():
+        node = hp
+        *path, last = k.split(".")
+        for q in path:
+            node = node[q]
+        node[last] = v
+    path = tmp_path / "hp.yaml"
+    yaml.safe_dump(hp, open(path, "w"))
+    return str(path)
+
+
+def load_formula(model):
+    sd = model.state_dict()
+    for k, v in O.formula_params().items():
+        sd[k].copy_(torch.from_numpy(v))
+
+
+def test_train_step_order_matches_reference_G4(tmp_path, golden):
+    """Two Trainer.Train_Steps at dropout 0 (fp32 kernels) reproduce the reference's post-AdamW parameters."""
+    from speaker_embedding_torch_amd.Train import Trainer
+    hp_path = write_hp(tmp_path, dropout=0.0, **{"Train.Batch.Train.Speaker": 4, "Train.Batch.Train.Pattern_per_Speaker": 5})
+    tr = Trainer(hp_path, datasets={})
+    load_formula(tr.model)
+    x = torch.from_numpy(O.formula_mel(1, 20, 80, 160))
+    tr.Train_Step(x)
+    names = [n for n, _ in O.param_specs()]
+    params = dict(tr.model.named_parameters())
+    for i, n in enumerate(names):
+        s = params[n].detach().double().sum().item()
+        assert abs(s - golden["G4_param_sum"][i]) < 1e-5 * max(1.0, abs(golden["G4_param_sum"][i])) + 5e-4, n
+        k = min(8, params[n].numel())
+        assert np.abs(params[n].detach().reshape(-1)[:k].cpu().numpy() - golden["G4_param_head"][i][:k]).max() < 5e-6, n
+    loss2 = tr.Train_Step(x)
+    assert abs(loss2.item() - float(golden["G4_loss_step2"][0])) < 2e-5
+    for i, n in enumerate(names):
+        s = params[n].detach().double().sum().item()
+        assert abs(s - golden["G4_param_sum_step2"][i]) < 1e-5 * max(1.0, abs(golden["G4_param_sum_step2"][i])) + 1e-3, n
+    assert tr.steps == 2
+
+
+def test_trainer_epoch_checkpoint_resume_and_inferencer(tmp_path):
+    from speaker_embedding_torch_amd.Inference import Inferencer
+    from speaker_embedding_torch_amd.Train import Trainer
+    pat = tmp_path / "patterns"
+    make_patterns(str(pat), speakers=6, files=5)
+    hp_path = write_hp(tmp_path, bf16=True, **{
+        "Train.Train_Pattern.Path": str(pat), "Train.Eval_Pattern.Path": str(pat),
+        "Train.Batch.Train.Speaker": 3, "Train.Batch.Train.Pattern_per_Speaker": 4,
+        "Train.Batch.Eval.Speaker": 3, "Train.Batch.Eval.Pattern_per_Speaker": 4,
+        "Train.Frame_Length.Min": 60, "Train.Frame_Length.Max": 90, "Train.Max_Step": 4,
+        "Train.Checkpoint_Save_Interval": 2, "Train.Logging_Interval": 2, "Train.Evaluation_Interval": 4,
+        "Train.Inference_Interval": 4})
+    tr = Trainer(hp_path)
+    tr.Train()
+    assert tr.steps == 4
+    ck = os.path.join(tr.hp.Checkpoint_Path, "S_4.pt")
+    assert os.path.exists(ck) and os.path.exists(os.path.join(tr.hp.Checkpoint_Path, "S_2.pt"))
+    state = torch.load(ck, map_location="cpu", weights_only=True)
+    assert set(state) == {"Model", "Optimizer", "Scheduler", "Steps"} and state["Steps"] == 4
+    assert len(state["Model"]) == 44 and "positional_encoding.pe" in state["Model"]
+    assert os.path.exists(os.path.join(tr.hp.Checkpoint_Path, "Hyper_Parameters.yaml"))
+    ev = tr.Evaluation_Epoch()
+    assert np.isfinite(ev["Loss/Embedding"])
+    emb, speakers = tr.Inference_Epoch()
+    assert emb.shape == (len(speakers), 256) and np.allclose(np.linalg.norm(emb, axis=1), 1, atol=1e-4)
+    # auto-resume from the newest checkpoint (Train.py:270-282)
+    tr2 = Trainer(hp_path)
+    assert tr2.steps == 4
+    for (n1, p1), (n2, p2) in zip(tr.model.state_dict().items(), tr2.model.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1.cpu(), p2.cpu())
+    # Inferencer: multi-slice d-vectors from .npy mels, equal to model(mels, Samples) on the same windows
+    inf = Inferencer(hp_path, ck, batch_size=3)
+    rng = np.random.default_rng(1)
+    paths = []
+    for i in range(5):
+        p = str(tmp_path / f"utt{i}.npy")
+        np.save(p, rng.standard_normal((80, 200 + 7 * i)).astype(np.float32))
+        paths.append(p)
+    np.random.seed(3)
+    emb, labels = inf.Inference(paths + [str(tmp_path / "missing.npy")], list("abcde") + ["x"])
+    assert emb.shape == (5, 256) and labels == list("abcde")
+    assert torch.allclose(emb.norm(dim=1), torch.ones(5, device=emb.device), atol=1e-4)
+    with pytest.raises(NotImplementedError):
+        inf.Inference([__file__], ["wav"])
+
+
+def _dp_gpu_worker(rank, world, port, hp_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, REPO)
+    from speaker_embedding_torch_amd import distributed as D
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)   # one GPU box: gloo carries the CUDA buffers
+    torch.cuda.set_device(0)
+    hp = Load_Hyper_Parameters(hp_path)
+    torch.manual_seed(100 + rank)                                # different init per rank: broadcast must fix it
+    model = GE2E(hp, precision="fp32", seed=7).cuda()
+    model = D.apply_gradient_allreduce(model)
+    model.train()
+    crit = GE2E_Loss().cuda()
+    x = torch.from_numpy(O.formula_mel(20 + rank, 8, 80, 48, logmel=True)).cuda()
+    crit(model(x), 4).backward()
+    torch.cuda.synchronize()
+    flat = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu()
+    w = torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()
+    out[rank] = (flat, w, list(model._grad_sync.buckets_seen))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_data_parallel_gradient_mean(tmp_path):
+    """Each rank: own batch, local loss (Train.py:90-99); gradients = mean over ranks, bucket by bucket."""
+    import torch.multiprocessing as mp
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    hp_path = write_hp(tmp_path, dropout=0.0)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_gpu_worker, args=(2, 29600 + os.getpid() % 2000, hp_path, out), nprocs=2, join=True)
+    g0, w0, b0 = out[0]
+    g1, w1, b1 = out[1]
+    assert torch.equal(w0, w1) and torch.allclose(g0, g1, atol=0, rtol=0)
+    # single-process reference: same weights, both batches, average of the two gradients
+    hp = Load_Hyper_Parameters(hp_path)
+    model = GE2E(hp, precision="fp32", seed=7).cuda()
+    torch.nn.utils.vector_to_parameters(w0.cuda(), model.parameters())
+    model.train()
+    crit = GE2E_Loss().cuda()
+    acc = 0
+    for r in range(2):
+        model.zero_grad()
+        crit(model(torch.from_numpy(O.formula_mel(20 + r, 8, 80, 48, logmel=True)).cuda()), 4).backward()
+        acc = acc + torch.cat([p.grad.flatten() for p in model.parameters()]).cpu()
+    assert rel_l2(g0.numpy(), (acc / 2).numpy()) < 1e-4
+    total = g0.numel()
+    assert len(b0) == 5 and sum(c for _, c in b0) == total         # tail, 3 layers, prenet: disjoint cover
+    assert b0[0][0] + b0[0][1] == total and b0[-1][0] == 0

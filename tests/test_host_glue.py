@@ -1,0 +1,124 @@
+"""CPU tests of the host-side glue: pattern datasets, collaters, the bucketed gradient mean (gloo, world 2),
+and the loud failure of Trainer / Inferencer without a GPU."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from speaker_embedding_torch_amd import Datasets
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml")
+
+
+def make_patterns(root, speakers=5, files=4, mel=80):
+    """Tiny pattern directory in the reference's on-disk format (Pattern_Generator.py:191-198)."""
+    rng = np.random.default_rng(0)
+    table = {}
+    for s in range(speakers):
+        spk = f"SPK{s:02d}"
+        table[spk] = []
+        for f in range(files + (s % 2)):
+            name = f"{spk}/{f:03d}.PICKLE"
+            os.makedirs(os.path.join(root, spk), exist_ok=True)
+            t = int(rng.integers(40, 300))
+            with open(os.path.join(root, name), "wb") as fh:
+                pickle.dump({"Mel": rng.standard_normal((mel, t)).astype(np.float16), "Speaker": spk, "Dataset": "SYN"}, fh)
+            table[spk].append(name)
+    with open(os.path.join(root, "METADATA.PICKLE"), "wb") as fh:
+        pickle.dump({"File_List_by_Speaker_Dict": table}, fh)
+    return table
+
+
+def test_correction_crop_and_reflect_pad():
+    np.random.seed(0)
+    x = np.arange(80 * 50, dtype=np.float32).reshape(80, 50)
+    c = Datasets.Correction(x, 20)
+    assert c.shape == (80, 20)
+    start = int(c[0, 0])
+    assert np.array_equal(c, x[:, start:start + 20])
+    p = Datasets.Correction(x, 57)           # deficit 7 -> 3 left, 4 right, reflect (no edge repeat)
+    assert p.shape == (80, 57)
+    assert np.array_equal(p[:, 3:53], x)
+    assert np.array_equal(p[:, :3], x[:, 3:0:-1]) and np.array_equal(p[:, 53:], x[:, -2:-6:-1])
+    assert np.array_equal(Datasets.Correction(x, 50), x)
+
+
+def test_dataset_and_collaters(tmp_path):
+    make_patterns(str(tmp_path))
+    ds = Datasets.Dataset(str(tmp_path), "METADATA.PICKLE", pattern_per_speaker=5)
+    assert len(ds) == 2                       # only speakers with >= 5 files survive
+    ds = Datasets.Dataset(str(tmp_path), "METADATA.PICKLE", pattern_per_speaker=3)
+    assert len(ds) == 5
+    item = ds[1]
+    assert len(item) == 3 and item[0][0].dtype == np.float16 and item[0][1] == ds.speakers[1]
+    col = Datasets.Collater(60, 70)
+    batch = col([ds[0], ds[3]])
+    assert batch.dtype == torch.float32 and batch.shape[:2] == (6, 80) and 60 <= batch.shape[2] <= 70
+    assert batch.is_contiguous()
+    inf = Datasets.Inference_Collater(samples=5, frame_length=64, overlap_length=32)
+    assert inf.required_length == 192
+    feats, speakers = inf([ds[0], ds[2]])
+    assert feats.shape == (6 * 5, 80, 64) and len(speakers) == 6
+    # consecutive windows overlap by 32 frames
+    assert torch.equal(feats[0][:, 32:], feats[1][:, :32])
+    sub = Datasets.Dataset(str(tmp_path), "METADATA.PICKLE", pattern_per_speaker=3, num_speakers=2)
+    assert len(sub) == 2
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from speaker_embedding_torch_amd import distributed as D
+    D.init_distributed(rank, world, dist_backend="gloo")
+    torch.manual_seed(rank)
+    lin = torch.nn.Linear(4, 3)
+    lin = D.apply_gradient_allreduce(lin)           # broadcast rank 0's weights
+    w = lin.weight.detach().clone()
+    sync = lin._grad_sync
+    grads = torch.arange(10, dtype=torch.float32) * (rank + 1)
+    cb = sync.bucket_callback(grads)
+    for off, cnt in ((7, 3), (3, 4), (0, 3)):        # the order the HIP backward reports buckets in
+        cb(None, off, cnt)
+    sync.finish(grads)
+    red = D.reduce_tensor(torch.tensor([float(rank + 1)]), world)
+    out[rank] = (w, grads, red, list(sync.buckets_seen))
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_mean_gloo_world2():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    w0, g0, r0, b0 = out[0]
+    w1, g1, r1, b1 = out[1]
+    assert torch.equal(w0, w1)                                   # rank 0's parameters everywhere
+    expect = torch.arange(10, dtype=torch.float32) * 1.5         # mean of x1 and x2
+    assert torch.allclose(g0, expect) and torch.allclose(g1, expect)
+    assert float(r0) == float(r1) == 1.5
+    assert b0 == [(7, 3), (3, 4), (0, 3)]
+
+
+def test_trainer_and_inferencer_need_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from speaker_embedding_torch_amd.Inference import Inferencer
+    from speaker_embedding_torch_amd.Train import Trainer
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Trainer(HP, datasets={})
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Inferencer(HP)
+
+
+def test_hyper_parameters_yaml_has_reference_schema():
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    hp = Load_Hyper_Parameters(HP)
+    assert hp.Sound.Mel_Dim == 80 and hp.GE2E.Embedding_Size == 256 and hp.GE2E.Transformer.Head == 4
+    assert hp.Train.Batch.Train.Speaker == 64 and hp.Train.Batch.Train.Pattern_per_Speaker == 15
+    assert hp.Train.Inference.Samples == 5 and hp.Train.ADAM.Epsilon == 1e-6
+    for key in ("Checkpoint_Path", "Log_Path", "Use_Mixed_Precision", "Use_Multi_GPU", "Device"):
+        assert hasattr(hp, key)
