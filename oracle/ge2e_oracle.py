@@ -140,23 +140,37 @@ def drop_key(seed: int, step: int, site: int) -> int:
 
 
 def drop_threshold(p: float) -> int:
-    return int(math.floor(p * float(1 << 24)))
+    return int(math.floor(p * 65536.0))
+
+
+def drop_keep_at(key: int, idx, p: float):
+    """keep[idx]: word = mix32((idx >> 1) ^ key); field = word >> 16 if idx odd else word & 0xFFFF;
+    keep = field >= floor(p * 2^16).  One hash serves an index pair (see csrc/common.cuh)."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    w = _mix32(((idx >> np.uint64(1)) ^ np.uint64(key)) & _M32)
+    field = np.where((idx & np.uint64(1)).astype(bool), w >> np.uint32(16), w & np.uint32(0xFFFF))
+    return field >= np.uint32(drop_threshold(p))
 
 
 def drop_keep(key: int, count: int, p: float, start: int = 0):
-    """keep[i] = (mix32((i * 0x9E3779B1) ^ key) >> 8) >= floor(p * 2^24), i = element index."""
-    idx = np.arange(start, start + count, dtype=np.uint64)
-    h = _mix32((((idx * np.uint64(0x9E3779B1)) & _M32) ^ np.uint64(key)) & _M32)
-    return (h >> np.uint32(8)) >= np.uint32(drop_threshold(p))
+    return drop_keep_at(key, np.arange(start, start + count, dtype=np.uint64), p)
 
 
-def _dropout(x, key, p, train):
-    """inverted dropout as torch.nn.Dropout (scale kept values by 1/(1-p))."""
+def _dropout(x, key, p, train, index=None):
+    """inverted dropout as torch.nn.Dropout (scale kept values by 1/(1-p)); element counter = flat C-order
+    index unless `index` (same shape as x) is given."""
     if (not train) or p <= 0.0:
         return x, None
-    keep = drop_keep(key, x.size, p).reshape(x.shape)
+    keep = (drop_keep(key, x.size, p).reshape(x.shape) if index is None else drop_keep_at(key, index, p))
     scale = x.dtype.type(1.0 / (1.0 - p))
     return x * keep * scale, keep
+
+
+def attn_drop_index(n, heads, t):
+    """counter of P[n, h, i, j] = ((n*H + h)*T + i) * T4 + j with T4 = T rounded up to a multiple of 4."""
+    t4 = (t + 3) // 4 * 4
+    rows = np.arange(n * heads * t, dtype=np.uint64).reshape(n, heads, t, 1)
+    return rows * np.uint64(t4) + np.arange(t, dtype=np.uint64).reshape(1, 1, 1, t)
 
 
 SITE_PE = 0
@@ -249,7 +263,8 @@ def encoder_forward(params, x, samples=1, heads=4, train=False, seed=0, step=0,
         s = s - s.max(-1, keepdims=True)
         e = np.exp(s)
         prob = e / e.sum(-1, keepdims=True)
-        probd, keep_a = _dropout(prob, drop_key(seed, step, site_attn(l)), p_tf, train)
+        probd, keep_a = _dropout(prob, drop_key(seed, step, site_attn(l)), p_tf, train,
+                                 index=attn_drop_index(n, heads, t) if (train and p_tf > 0) else None)
         o = (probd @ v).transpose(0, 2, 1, 3).reshape(n, t, d)
         a = o @ params[p + "self_attn.out_proj.weight"].T + params[p + "self_attn.out_proj.bias"]
         a, keep_sa = _dropout(a, drop_key(seed, step, site_sa(l)), p_tf, train)

@@ -105,11 +105,13 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
         const float inv = 1.0f / cross4_sum(sum);
-        const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)p.T;
+        // dropout counter of P[query][key] = (head_row * T + query) * T4 + key, T4 = T rounded up to 4 (aligned quads)
+        const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
 #pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = drop_apply(p.drop, ibase + (uint32_t)(16 * t + 4 * g + r), s[t][r] * inv);
+        for (int t = 0; t < NT16; ++t) {
+            s[t] *= inv;
+            drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t]);
+        }
 
         f32x4 oacc[4];
 #pragma unroll
@@ -183,20 +185,20 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
         const float inv = 1.0f / cross4_sum(sum);
-        const uint32_t ibase = (hbase + (uint32_t)qrow) * (uint32_t)p.T;
+        const uint32_t T4 = (uint32_t)((p.T + 3) & ~3);
+        const uint32_t ibase = (hbase + (uint32_t)qrow) * T4;
         f32x4 dp[NT16];
         float delta = 0.0f;
 #pragma unroll
         for (int t = 0; t < NT16; ++t) {
             dp[t] = attn::tile_dot<T>(bufB, t, dof, i, g);     // d(P dropped)^T[key][query]
             __builtin_amdgcn_sched_barrier(0);
+            drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp[t]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = s[t][r] * inv;
-                const float dv = drop_apply(p.drop, ibase + (uint32_t)(16 * t + 4 * g + r), dp[t][r]);
                 s[t][r] = pr;
-                dp[t][r] = dv;
-                delta += pr * dv;
+                delta += pr * dp[t][r];
             }
         }
         delta = cross4_sum(delta);
@@ -254,7 +256,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
                     const int q = 16 * t + 4 * g + r;
                     const bool ok = (q < p.T) && vk;
                     const float pr = ok ? exp_prec<T>(sa[r] * p.scale - m4[r]) * l4[r] : 0.0f;
-                    const uint32_t idx = (hbase + (uint32_t)q) * (uint32_t)p.T + (uint32_t)krow;
+                    const uint32_t idx = (hbase + (uint32_t)q) * (uint32_t)((p.T + 3) & ~3) + (uint32_t)krow;
                     const float dv = ok ? drop_apply(p.drop, idx, da[r]) : 0.0f;
                     pd[u][r] = drop_apply(p.drop, idx, pr);
                     ds[u][r] = ok ? pr * (dv - d4[r]) * p.scale : 0.0f;

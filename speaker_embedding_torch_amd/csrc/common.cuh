@@ -135,15 +135,18 @@ template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char
 }
 
 // ---------------------------------------------------------------------------------------------
-// counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep
-//   keep(idx) = (mix32((idx * 0x9E3779B1) ^ key) >> 8) >= thr,   thr = floor(p * 2^24)
+// counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep.  One 32-bit hash serves the
+// two elements of an index pair (v_mul_lo_u32 is quarter rate, so hashes are the cost):
+//   word(idx) = mix32((idx >> 1) ^ key);  field = idx odd ? word >> 16 : word & 0xFFFF;
+//   keep(idx) = field >= thr,  thr = floor(p * 65536)
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
 __host__ __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
-    return (mix32((idx * 0x9E3779B1u) ^ key) >> 8) >= thr;
+    const uint32_t w = mix32((idx >> 1) ^ key);
+    return ((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
 }
 struct Drop {            // thr == 0  <=>  dropout inactive (eval mode or p == 0)
     uint32_t key, thr;
@@ -152,6 +155,18 @@ struct Drop {            // thr == 0  <=>  dropout inactive (eval mode or p == 0
 __device__ __forceinline__ float drop_apply(const Drop& d, uint32_t idx, float v) {
     if (d.thr == 0) return v;
     return drop_keep(idx, d.key, d.thr) ? v * d.scale : 0.0f;
+}
+// keep-mask (bit r <-> element base + r) of 4 consecutive elements, base % 4 == 0: two hashes
+__device__ __forceinline__ uint32_t drop_mask4(const Drop& d, uint32_t base) {
+    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    return (uint32_t)((h0 & 0xFFFFu) >= d.thr) | ((uint32_t)((h0 >> 16) >= d.thr) << 1) |
+           ((uint32_t)((h1 & 0xFFFFu) >= d.thr) << 2) | ((uint32_t)((h1 >> 16) >= d.thr) << 3);
+}
+__device__ __forceinline__ void drop_apply4(const Drop& d, uint32_t base, f32x4& v) {
+    if (d.thr == 0) return;
+    const uint32_t m = drop_mask4(d, base);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = ((m >> r) & 1u) ? v[r] * d.scale : 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------

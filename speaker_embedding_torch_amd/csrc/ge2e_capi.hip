@@ -3,6 +3,7 @@
 // out_proj GEMM+LN, FFN1 GEMM, FFN2 GEMM+LN} + tail.  Everything is enqueued on the caller's stream.
 #include "../../include/ge2e_hip.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -138,7 +139,7 @@ Drop make_drop(bool active, float p, uint64_t seed, uint64_t step, int site) {
     Drop d{0u, 0u, 1.0f};
     if (!active || p <= 0.0f) return d;
     d.key = ge2e_drop_key(seed, step, site);
-    d.thr = (uint32_t)std::floor((double)p * 16777216.0);
+    d.thr = (uint32_t)std::floor((double)p * 65536.0);
     d.scale = (float)(1.0 / (1.0 - (double)p));
     return d;
 }
@@ -189,7 +190,7 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if (a.K % BK != 0 || a.N % BN != 0 || a.M <= 0)
         return fail(h, GE2E_EUNSUPPORTED, "gemm: N must be a multiple of the tile and K of the k-step");
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const size_t smem = 2 * (size_t)(BM + BN) * 128;
+    const size_t smem = std::max<size_t>(2 * (size_t)(BM + BN) * 128, (size_t)BM * (BN * sizeof(T) + 16));
     auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD>;
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM,
                  2.0 * a.M * a.N * (ALOAD == ALOAD_MEL ? a.mel : a.K));
@@ -715,7 +716,7 @@ uint32_t ge2e_drop_key(uint64_t seed, uint64_t step, int site) {
 }
 
 int ge2e_drop_keep(uint32_t key, uint32_t index, float p) {
-    const uint32_t thr = (uint32_t)std::floor((double)p * 16777216.0);
+    const uint32_t thr = (uint32_t)std::floor((double)p * 65536.0);
     return drop_keep(index, key, thr) ? 1 : 0;
 }
 

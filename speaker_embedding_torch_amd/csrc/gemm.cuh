@@ -136,29 +136,52 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     }
 
     // ------------------------------------------------------------------ epilogue
+    // All global traffic of the epilogue is 16 bytes per lane along rows: the residual / mask / addend tile
+    // comes in through LDS, each lane transforms its 4-column groups in place, and the finished tile goes out
+    // with full-line stores (the MFMA layout itself would give 32-byte segments per row).
+    constexpr bool NEEDS_R = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
+    constexpr int CPRC = BN * (int)sizeof(T) / 16;        // 16-byte chunks per tile row
+    constexpr int LDC = BN * (int)sizeof(T) + 16;         // LDS row stride of the staged tile
+    constexpr int NCC = BM * CPRC / 256;                  // chunks per thread
+    unsigned char* const Cs = smem;                        // main loop ended with a barrier: LDS is free
     T* const C = (T*)p.C;
-    const T* const Rm = (const T*)p.R;
+    if constexpr (NEEDS_R) {
+        const unsigned char* Rg = (const unsigned char*)p.R;
+#pragma unroll
+        for (int q0 = 0; q0 < NCC; q0 += 8) {              // at most 8 x 16 B in flight per thread
+            u32x4 rr[8];
+#pragma unroll
+            for (int q = 0; q < 8 && q0 + q < NCC; ++q) {
+                const int id = tid + 256 * (q0 + q), row = id / CPRC, c = id % CPRC, gr = m0 + row;
+                rr[q] = gr < p.M ? *(const u32x4*)(Rg + ((size_t)gr * p.ldr + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int q = 0; q < 8 && q0 + q < NCC; ++q) {
+                const int id = tid + 256 * (q0 + q);
+                *(u32x4*)(Cs + (id / CPRC) * LDC + (id % CPRC) * 16) = rr[q];
+            }
+        }
+        __syncthreads();
+    }
     float dal = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int row = m0 + wm * WM + mt * 16 + i;
-        const bool ok = row < p.M;
-        const int colb = n0 + wn * WN + 4 * g;
+        const int lrow = wm * WM + mt * 16 + i;            // row inside the tile
+        const int row = m0 + lrow;
+        const int lcolb = wn * WN + 4 * g, colb = n0 + lcolb;
+        T* const crow = (T*)(Cs + lrow * LDC);
         if constexpr (EPI == EPI_LN) {
             float sum = 0.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = colb + nt * 16;
                 const f32x4 b4 = *(const f32x4*)(p.bias + col);
-                f32x4 r4 = f32x4{0, 0, 0, 0};
-                if (ok) r4 = load4(Rm + (size_t)row * p.ldr + col);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[mt][nt][r] + b4[r];
-                    v = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), v) + r4[r];
-                    acc[mt][nt][r] = v;
-                    sum += v;
-                }
+                const f32x4 r4 = load4(crow + lcolb + nt * 16);
+                f32x4 v4 = acc[mt][nt] + b4;
+                drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v4);
+                v4 += r4;
+                acc[mt][nt] = v4;
+                sum += v4[0] + v4[1] + v4[2] + v4[3];
             }
             const float mean = cross4_sum(sum) * (1.0f / (float)BN);
             float sq = 0.0f;
@@ -167,64 +190,72 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float d = acc[mt][nt][r] - mean; sq += d * d; }
             const float rstd = 1.0f / sqrtf(cross4_sum(sq) * (1.0f / (float)BN) + p.eps);
-            if (ok) {
-                if (g == 0 && p.rstd) p.rstd[row] = rstd;
+            if (g == 0 && p.rstd && row < p.M) p.rstd[row] = rstd;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int col = colb + nt * 16;
-                    const f32x4 g4 = *(const f32x4*)(p.gamma + col), be4 = *(const f32x4*)(p.beta + col);
-                    store4(C + (size_t)row * p.ldc + col,
-                           (acc[mt][nt][0] - mean) * rstd * g4[0] + be4[0], (acc[mt][nt][1] - mean) * rstd * g4[1] + be4[1],
-                           (acc[mt][nt][2] - mean) * rstd * g4[2] + be4[2], (acc[mt][nt][3] - mean) * rstd * g4[3] + be4[3]);
-                }
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = colb + nt * 16;
+                const f32x4 g4 = *(const f32x4*)(p.gamma + col), be4 = *(const f32x4*)(p.beta + col);
+                store4(crow + lcolb + nt * 16,
+                       (acc[mt][nt][0] - mean) * rstd * g4[0] + be4[0], (acc[mt][nt][1] - mean) * rstd * g4[1] + be4[1],
+                       (acc[mt][nt][2] - mean) * rstd * g4[2] + be4[2], (acc[mt][nt][3] - mean) * rstd * g4[3] + be4[3]);
             }
         } else {
             int t = 0;
-            if constexpr (EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) t = row % p.T;
+            if constexpr (EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) t = row < p.M ? row % p.T : 0;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = colb + nt * 16;
                 f32x4 v = acc[mt][nt];
-                if (!ok) continue;
                 if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) {
                     const f32x4 b4 = *(const f32x4*)(p.bias + col);
                     v += b4;
                 }
                 if constexpr (EPI == EPI_BIAS_RELU_DROP) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), fmaxf(v[r], 0.0f));
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v);
                 }
                 if constexpr (EPI == EPI_PRENET) {
                     const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
                     const float al = *p.alpha;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v[r] = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), fmaxf(v[r], 0.0f) + al * pe4[r]);
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) + al * pe4[r];
+                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v);
                 }
                 if constexpr (EPI == EPI_PRENET_BWD) {
-                    // v = prenet pre-activation (recomputed); R = dL/dh0 -> masked gradient of the pre-activation
+                    // v = prenet pre-activation (recomputed); staged tile = dL/dh0 -> masked gradient of the pre-activation
                     const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
-                    const f32x4 d4 = load4(Rm + (size_t)row * p.ldr + col);
+                    f32x4 d4 = load4(crow + lcolb + nt * 16);
+                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, d4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float gv = drop_apply(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)(col + r), d4[r]);
+                        const float gv = row < p.M ? d4[r] : 0.0f;
                         dal += gv * pe4[r];
                         v[r] = v[r] > 0.0f ? gv : 0.0f;
                     }
                 }
                 if constexpr (EPI == EPI_MASK) {
-                    const f32x4 m4 = load4(Rm + (size_t)row * p.ldr + col);
+                    const f32x4 m4 = load4(crow + lcolb + nt * 16);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
                 }
-                if constexpr (EPI == EPI_ADD) v += load4(Rm + (size_t)row * p.ldr + col);
-                store4(C + (size_t)row * p.ldc + col, v[0], v[1], v[2], v[3]);
+                if constexpr (EPI == EPI_ADD) v += load4(crow + lcolb + nt * 16);
+                store4(crow + lcolb + nt * 16, v[0], v[1], v[2], v[3]);
             }
         }
     }
+    __syncthreads();
+    {
+        unsigned char* Cg = (unsigned char*)C;
+#pragma unroll
+        for (int q = 0; q < NCC; ++q) {
+            const int id = tid + 256 * q, row = id / CPRC, c = id % CPRC, gr = m0 + row;
+            if (gr < p.M) *(u32x4*)(Cg + ((size_t)gr * p.ldc + n0) * sizeof(T) + c * 16) = *(const u32x4*)(Cs + row * LDC + c * 16);
+        }
+    }
     if constexpr (EPI == EPI_PRENET_BWD) {
-        float* red = (float*)smem;      // main loop ended with a barrier; LDS is free
+        __syncthreads();
+        float* red = (float*)smem;
         const float s = block256_sum(dal, red);
         if (tid == 0) atomicAdd(p.dalpha, s);
     }

@@ -105,9 +105,8 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
         for (int r = 0; r < 4; ++r) dx[r] = rs * (dxh[r] - s1 - xh[r] * s2);
         store4((T*)p.dpre + (size_t)row * 256 + c0, dx[0], dx[1], dx[2], dx[3]);
         if (p.dmask) {
-            const uint32_t ib = (uint32_t)row * 256u + (uint32_t)c0;
-            store4((T*)p.dmask + (size_t)row * 256 + c0, drop_apply(p.drop, ib, dx[0]), drop_apply(p.drop, ib + 1, dx[1]),
-                   drop_apply(p.drop, ib + 2, dx[2]), drop_apply(p.drop, ib + 3, dx[3]));
+            drop_apply4(p.drop, (uint32_t)row * 256u + (uint32_t)c0, dx);
+            store4((T*)p.dmask + (size_t)row * 256 + c0, dx[0], dx[1], dx[2], dx[3]);
         }
     }
 #pragma unroll

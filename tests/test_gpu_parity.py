@@ -172,6 +172,9 @@ def test_bf16_train_step_vs_oracle(mods, n, t, P, p, tag):
     assert abs(loss.item() - float(loss_ref)) < 2e-2 * max(1.0, abs(float(loss_ref)))
     for name, prm in m.named_parameters():
         g, r = prm.grad.cpu().numpy().ravel().astype(np.float64), grads_ref[name].ravel().astype(np.float64)
+        if g.size == 1:      # alpha: one scalar = a sum over R*256 terms of both signs; bound it by the terms' scale
+            assert abs(g[0] - r[0]) < 0.05 * np.linalg.norm(grads_ref["prenet.bias"]), name
+            continue
         cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
         assert cos > 0.98 and rel_l2(g, r) < 0.25, (name, cos)
 
