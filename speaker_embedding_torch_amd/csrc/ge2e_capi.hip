@@ -87,6 +87,9 @@ struct Layout {
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
+    // last layer: only frame 0 of its output is consumed, so everything after its K/V projection lives on
+    // COMPACT rows (one per utterance): o/h1/f/h2 of that layer and this backward scratch
+    size_t c_dH = 0, c_dHb = 0, c_dP = 0, c_dM = 0, c_dF = 0, c_dO = 0, c_dQ0 = 0, c_tmp = 0;
     size_t total = 0;
 };
 
@@ -110,19 +113,26 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     L.wqT = take(d * d * 4);
     L.pe_t = take((size_t)t * d * 4);
     L.h0 = take(R * d * e);
+    const int last = c.layers - 1;
     if (train) {
         for (int l = 0; l < c.layers; ++l) {
-            L.qkv[l] = take(R * 3 * d * e); L.o[l] = take(R * d * e);
-            L.h1[l] = take(R * d * e);      L.rstd1[l] = take(R * 4);
-            L.f[l] = take(R * f * e);       L.h2[l] = take(R * d * e);
-            L.rstd2[l] = take(R * 4);
+            const size_t Rl = l == last ? (size_t)n : R;
+            L.qkv[l] = take(R * 3 * d * e); L.o[l] = take(Rl * d * e);
+            L.h1[l] = take(Rl * d * e);     L.rstd1[l] = take(Rl * 4);
+            L.f[l] = take(Rl * f * e);      L.h2[l] = take(Rl * d * e);
+            L.rstd2[l] = take(Rl * 4);
         }
     } else {        // eval: layers reuse one set of buffers; h2 overwrites the layer input
-        const size_t qkv = take(R * 3 * d * e), o = take(R * d * e), h1 = take(R * d * e), ff = take(R * f * e);
-        for (int l = 0; l < c.layers; ++l) {
+        const size_t qkv = take(R * 3 * d * e);
+        size_t o = 0, h1 = 0, ff = 0;
+        if (c.layers > 1) { o = take(R * d * e); h1 = take(R * d * e); ff = take(R * f * e); }
+        for (int l = 0; l < last; ++l) {
             L.qkv[l] = qkv; L.o[l] = o; L.h1[l] = h1; L.f[l] = ff; L.h2[l] = L.h0;
             L.rstd1[l] = L.rstd2[l] = (size_t)-1;
         }
+        L.qkv[last] = qkv; L.o[last] = take((size_t)n * d * e); L.h1[last] = take((size_t)n * d * e);
+        L.f[last] = take((size_t)n * f * e); L.h2[last] = take((size_t)n * d * e);
+        L.rstd1[last] = L.rstd2[last] = (size_t)-1;
     }
     L.xhat_f = take((size_t)n * d * 4); L.rstd_f = take((size_t)n * 4);
     L.zm = take((size_t)n * d * 4);     L.nrm = take((size_t)n * 4);
@@ -130,6 +140,9 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     if (train) {
         L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dP = take(R * d * e); L.dM = take(R * d * e);
         L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
+        const size_t nn = (size_t)n;
+        L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
+        L.c_dF = take(nn * f * e); L.c_dO = take(nn * d * e); L.c_dQ0 = take(nn * d * e); L.c_tmp = take(nn * d * e);
     }
     L.total = off;
     return L;
@@ -261,6 +274,15 @@ int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bw
     }
 }
 
+template <typename T>
+int launch_attn_q0(ge2e_handle h, hipStream_t st, const AttnQ0Args& a, int n, bool bwd) {
+    if (a.T > 64 * attn::Q0_KPL || a.H > 4) return fail(h, GE2E_EUNSUPPORTED, "q0 attention: frames > 320 or heads > 4");
+    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 10.0 : 4.0) * a.T * 64.0 * n * a.H);
+    if (bwd) { auto kern = attn_q0_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+    else { auto kern = attn_q0_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+    return 0;
+}
+
 int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_t ws_bytes, const Layout& L) {
     const ge2e_config& c = h->cfg;
     if (n <= 0 || t <= 0 || samples <= 0 || n % samples != 0) return fail(h, GE2E_EINVAL, "n_utts/frames/samples invalid");
@@ -322,48 +344,70 @@ int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, 
     }
     for (int l = 0; l < c.layers; ++l) {
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
-        {   // in_proj
+        // Only frame 0 of the LAST layer's output is consumed (Modules.py:54): that layer needs K and V of every
+        // frame but its query, out-projection, FFN and both LayerNorms for frame 0 only -> compact rows, one per
+        // utterance, addressed with stride `rmul` where the full-row index matters (residual, dropout counters).
+        const bool last = l == c.layers - 1;
+        const int Rl = last ? n : R, rmul = last ? t : 1;
+        const size_t esz = L.esz;
+        if (!last) {   // in_proj
             GemmArgs a{};
             a.A = hin; a.lda = d; a.W = ws + L.w_in[l]; a.ldw = d; a.C = ws + L.qkv[l]; a.ldc = 3 * d;
             a.M = R; a.N = 3 * d; a.K = d; a.bias = P[lp(l, L_IN_B)];
             CK((gemm128<T, EPI_BIAS>(h, st, a)));
+        } else {
+            GemmArgs a{};   // k | v of every frame
+            a.A = hin; a.lda = d; a.W = ws + L.w_in[l] + (size_t)d * d * esz; a.ldw = d;
+            a.C = ws + L.qkv[l] + (size_t)d * esz; a.ldc = 3 * d;
+            a.M = R; a.N = 2 * d; a.K = d; a.bias = P[lp(l, L_IN_B)] + d;
+            CK((gemm128<T, EPI_BIAS>(h, st, a)));
+            GemmArgs q{};   // q of frame 0: rows n*T of hin -> rows n*T of qkv
+            q.A = hin; q.lda = d * t; q.W = ws + L.w_in[l]; q.ldw = d; q.C = ws + L.qkv[l]; q.ldc = 3 * d * t;
+            q.M = n; q.N = d; q.K = d; q.bias = P[lp(l, L_IN_B)];
+            CK((gemm128<T, EPI_BIAS>(h, st, q)));
         }
-        {   // softmax(q k^T / 8) v per (utterance, head)
+        if (!last) {   // softmax(q k^T / 8) v per (utterance, head)
             AttnArgs a{};
             a.qkv = ws + L.qkv[l]; a.o = ws + L.o[l]; a.T = t; a.H = c.heads; a.D = d;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, false));
+        } else {
+            AttnQ0Args a{};
+            a.qkv = ws + L.qkv[l]; a.o0 = ws + L.o[l]; a.T = t; a.H = c.heads; a.D = d;
+            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
+            CK(launch_attn_q0<T>(h, st, a, n, false));
         }
         {   // out_proj + dropout1 + residual + norm1
             GemmArgs a{};
             a.A = ws + L.o[l]; a.lda = d; a.W = ws + L.w_out[l]; a.ldw = d; a.C = ws + L.h1[l]; a.ldc = d;
-            a.M = R; a.N = d; a.K = d; a.bias = P[lp(l, L_OUT_B)]; a.R = hin; a.ldr = d;
+            a.M = Rl; a.N = d; a.K = d; a.bias = P[lp(l, L_OUT_B)]; a.R = hin; a.ldr = d * rmul;
             a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)]; a.eps = c.ln_eps;
             a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
-            a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l));
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.drow_mul = rmul;
             CK(gemm_ln<T>(h, st, a));
         }
         {   // linear1 + ReLU + dropout
             GemmArgs a{};
             a.A = ws + L.h1[l]; a.lda = d; a.W = ws + L.w_l1[l]; a.ldw = d; a.C = ws + L.f[l]; a.ldc = c.ffn;
-            a.M = R; a.N = c.ffn; a.K = d; a.bias = P[lp(l, L_L1_B)];
-            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
+            a.M = Rl; a.N = c.ffn; a.K = d; a.bias = P[lp(l, L_L1_B)];
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ffh(l)); a.drow_mul = rmul;
             CK((gemm128<T, EPI_BIAS_RELU_DROP>(h, st, a)));
         }
         {   // linear2 + dropout2 + residual + norm2
             GemmArgs a{};
             a.A = ws + L.f[l]; a.lda = c.ffn; a.W = ws + L.w_l2[l]; a.ldw = c.ffn; a.C = ws + L.h2[l]; a.ldc = d;
-            a.M = R; a.N = d; a.K = c.ffn; a.bias = P[lp(l, L_L2_B)]; a.R = ws + L.h1[l]; a.ldr = d;
+            a.M = Rl; a.N = d; a.K = c.ffn; a.bias = P[lp(l, L_L2_B)]; a.R = ws + L.h1[l]; a.ldr = d;
             a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)]; a.eps = c.ln_eps;
             a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
-            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ff(l));
+            a.drop = make_drop(train, c.tf_dropout, seed, step, site_ff(l)); a.drow_mul = rmul;
             CK(gemm_ln<T>(h, st, a));
         }
     }
     {   // final LN at t = 0 -> slice mean -> projection -> L2 normalise
         TailArgs a{};
-        a.h = ws + L.h2[c.layers - 1]; a.T = t; a.samples = samples; a.N = n;
+        a.h = ws + L.h2[c.layers - 1]; a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
         a.gf = P[p_fn_w(c)]; a.bf = P[p_fn_b(c)]; a.wq = P[p_proj_w(c)]; a.wqT = (const float*)(ws + L.wqT); a.bq = P[p_proj_b(c)];
         a.eps = c.ln_eps;
         a.xhat = (float*)(ws + L.xhat_f); a.rstd = (float*)(ws + L.rstd_f);
@@ -389,105 +433,132 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     };
     hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
     if (e != hipSuccess) return fail_hip(h, e, "zero grads");
-    e = hipMemsetAsync(ws + L.dHa, 0, (size_t)R * d * L.esz, st);
-    if (e != hipSuccess) return fail_hip(h, e, "zero dH");
     {
         TailArgs a{};
-        a.T = t; a.samples = samples; a.N = n;
+        a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
         a.gf = P[p_fn_w(c)]; a.bf = P[p_fn_b(c)]; a.wq = P[p_proj_w(c)]; a.bq = P[p_proj_b(c)];
         a.xhat = (float*)(ws + L.xhat_f); a.rstd = (float*)(ws + L.rstd_f);
         a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm); a.emb = (float*)(ws + L.emb_keep);
-        a.d_emb = d_emb; a.d_raw = (float*)(ws + L.d_raw); a.dH = ws + L.dHa;
+        a.d_emb = d_emb; a.d_raw = (float*)(ws + L.d_raw); a.dH = ws + L.c_dH;
         a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dwq = G(p_proj_w(c)); a.dbq = G(p_proj_b(c));
         auto kern = tail_bwd_kernel<T>;
         GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
         GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, st, a);
         bucket(p_fn_w(c), p_proj_b(c));
     }
-    const int ln_grid = std::min(2048, (R + 3) / 4);
     // diagnostics only: GE2E_DEBUG_BWD_STOP=k returns after k layers so ge2e_debug_tap sees that layer's scratch
     const char* dbg_stop = std::getenv("GE2E_DEBUG_BWD_STOP");
     const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
+    const size_t esz = L.esz;
     for (int l = c.layers - 1; l >= 0; --l) {
         if (stop_after >= 0 && c.layers - 1 - l >= stop_after) return 0;
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
+        // the last layer runs on compact rows (one per utterance, frame 0) until its attention; see forward_impl
+        const bool last = l == c.layers - 1;
+        const int Rl = last ? n : R, rmul = last ? t : 1;
+        unsigned char* const b_dH = ws + (last ? L.c_dH : L.dHa);     // dL/d(layer output)
+        unsigned char* const b_dHb = ws + (last ? L.c_dHb : L.dHb);
+        unsigned char* const b_dP = ws + (last ? L.c_dP : L.dP);
+        unsigned char* const b_dM = ws + (last ? L.c_dM : L.dM);
+        unsigned char* const b_dF = ws + (last ? L.c_dF : L.dF);
+        unsigned char* const b_dO = ws + (last ? L.c_dO : L.dO);
+        const int ln_grid = std::min(2048, (Rl + 3) / 4);
         const Drop d_ff = make_drop(true, c.tf_dropout, seed, step, site_ff(l));
         const Drop d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
         const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
         {   // norm2 backward
             LnBwdArgs a{};
-            a.dy = ws + L.dHa; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
-            a.rstd = (const float*)(ws + L.rstd2[l]); a.dpre = ws + L.dP; a.dmask = d_ff.thr ? ws + L.dM : nullptr;
-            a.dgamma = G(lp(l, L_N2_W)); a.dbeta = G(lp(l, L_N2_B)); a.R = R; a.drop = d_ff;
+            a.dy = b_dH; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
+            a.rstd = (const float*)(ws + L.rstd2[l]); a.dpre = b_dP; a.dmask = d_ff.thr ? b_dM : nullptr;
+            a.dgamma = G(lp(l, L_N2_W)); a.dbeta = G(lp(l, L_N2_B)); a.R = Rl; a.drop = d_ff; a.drow_mul = rmul;
             auto kern = ln_bwd_kernel<T>;
-            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)R * d * L.esz * (d_ff.thr ? 4 : 3));
+            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)Rl * d * L.esz * (d_ff.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        unsigned char* gm = ws + (d_ff.thr ? L.dM : L.dP);
+        unsigned char* gm = d_ff.thr ? b_dM : b_dP;
         {   // dF = (dG W2) masked by ReLU/dropout of the hidden
             GemmArgs a{};
-            a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = ws + L.dF; a.ldc = c.ffn;
-            a.M = R; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
+            a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = b_dF; a.ldc = c.ffn;
+            a.M = Rl; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
             CK((gemm128<T, EPI_MASK>(h, st, a)));
         }
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
-            a.R = R; a.N = d; a.K = c.ffn;
+            a.R = Rl; a.N = d; a.K = c.ffn;
             CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
         }
         {
             WgradArgs a{};
-            a.Y = ws + L.dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
-            a.R = R; a.N = c.ffn; a.K = d;
+            a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
+            a.R = Rl; a.N = c.ffn; a.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
         }
         {   // dH1 = dPre2 + dF W1
             GemmArgs a{};
-            a.A = ws + L.dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = ws + L.dHb; a.ldc = d;
-            a.M = R; a.N = d; a.K = c.ffn; a.R = ws + L.dP; a.ldr = d;
+            a.A = b_dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = b_dHb; a.ldc = d;
+            a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, a)));
         }
         {   // norm1 backward
             LnBwdArgs a{};
-            a.dy = ws + L.dHb; a.y = ws + L.h1[l]; a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)];
-            a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = ws + L.dP; a.dmask = d_sa.thr ? ws + L.dM : nullptr;
-            a.dgamma = G(lp(l, L_N1_W)); a.dbeta = G(lp(l, L_N1_B)); a.R = R; a.drop = d_sa;
+            a.dy = b_dHb; a.y = ws + L.h1[l]; a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)];
+            a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = b_dP; a.dmask = d_sa.thr ? b_dM : nullptr;
+            a.dgamma = G(lp(l, L_N1_W)); a.dbeta = G(lp(l, L_N1_B)); a.R = Rl; a.drop = d_sa; a.drow_mul = rmul;
             auto kern = ln_bwd_kernel<T>;
-            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)R * d * L.esz * (d_sa.thr ? 4 : 3));
+            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        gm = ws + (d_sa.thr ? L.dM : L.dP);
+        gm = d_sa.thr ? b_dM : b_dP;
         {   // dO = dA Wo
             GemmArgs a{};
-            a.A = gm; a.lda = d; a.W = ws + L.w_outT[l]; a.ldw = d; a.C = ws + L.dO; a.ldc = d;
-            a.M = R; a.N = d; a.K = d;
+            a.A = gm; a.lda = d; a.W = ws + L.w_outT[l]; a.ldw = d; a.C = b_dO; a.ldc = d;
+            a.M = Rl; a.N = d; a.K = d;
             CK((gemm128<T, EPI_NONE>(h, st, a)));
         }
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
-            a.R = R; a.N = d; a.K = d;
+            a.R = Rl; a.N = d; a.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
         }
-        {
+        if (!last) {
             AttnArgs a{};
-            a.qkv = ws + L.qkv[l]; a.dout = ws + L.dO; a.dqkv = ws + L.dQKV; a.T = t; a.H = c.heads; a.D = d;
+            a.qkv = ws + L.qkv[l]; a.dout = b_dO; a.dqkv = ws + L.dQKV; a.T = t; a.H = c.heads; a.D = d;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, true));
-        }
-        {
-            WgradArgs a{};
-            a.Y = ws + L.dQKV; a.ldy = 3 * d; a.X = hin; a.ldx = d; a.dW = G(lp(l, L_IN_W)); a.ldw = d; a.db = G(lp(l, L_IN_B));
-            a.R = R; a.N = 3 * d; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
-        }
-        {   // dH(layer input) = dPre1 + dQKV Win
-            GemmArgs a{};
-            a.A = ws + L.dQKV; a.lda = 3 * d; a.W = ws + L.w_inT[l]; a.ldw = 3 * d; a.C = ws + L.dHa; a.ldc = d;
-            a.M = R; a.N = d; a.K = 3 * d; a.R = ws + L.dP; a.ldr = d;
-            CK((gemm128<T, EPI_ADD>(h, st, a)));
+            WgradArgs w{};
+            w.Y = ws + L.dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
+            w.R = R; w.N = 3 * d; w.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));
+            GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
+            g.A = ws + L.dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
+            g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP; g.ldr = d;
+            CK((gemm128<T, EPI_ADD>(h, st, g)));
+        } else {
+            AttnQ0Args a{};   // one query per (utterance, head): dK, dV for every frame, dQ for frame 0
+            a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = ws + L.dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
+            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
+            a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
+            CK(launch_attn_q0<T>(h, st, a, n, true));
+            WgradArgs wkv{};  // k | v rows of in_proj_weight from every frame
+            wkv.Y = ws + L.dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
+            wkv.dW = G(lp(l, L_IN_W)) + (size_t)d * d; wkv.ldw = d; wkv.db = G(lp(l, L_IN_B)) + d;
+            wkv.R = R; wkv.N = 2 * d; wkv.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, wkv)));
+            WgradArgs wq{};   // q rows from frame 0 of every utterance
+            wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
+            wq.R = n; wq.N = d; wq.K = d;
+            CK((launch_wgrad<T, ALOAD_ROW>(h, st, wq)));
+            GemmArgs g0{};    // frame-0 addend: dPre1 + dQ0 Wq   (compact)
+            g0.A = ws + L.c_dQ0; g0.lda = d; g0.W = ws + L.w_inT[l]; g0.ldw = 3 * d; g0.C = ws + L.c_tmp; g0.ldc = d;
+            g0.M = n; g0.N = d; g0.K = d; g0.R = b_dP; g0.ldr = d;
+            CK((gemm128<T, EPI_ADD>(h, st, g0)));
+            GemmArgs g{};     // dH(layer input) = dKV Wkv, plus the compact addend on frame-0 rows
+            g.A = ws + L.dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
+            g.C = ws + L.dHa; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
+            CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
         }
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
@@ -683,21 +754,24 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
                    size_t* offset_bytes, size_t* size_bytes) {
     if (!h || !name || !offset_bytes || !size_bytes) return GE2E_EINVAL;
     const Layout L = build_layout(h->cfg, n_utts, frames, train);
-    const size_t R = (size_t)L.R, d = h->cfg.emb, e = L.esz;
+    const size_t d = h->cfg.emb, e = L.esz;
+    size_t R = (size_t)L.R;
     std::string s(name);
     int l = 0;
     const size_t dot = s.find('.');
     std::string base = s;
     if (dot != std::string::npos) { base = s.substr(0, dot); l = std::atoi(s.c_str() + dot + 1); }
     if (l < 0 || l >= h->cfg.layers) return GE2E_EINVAL;
+    const bool lastl = l == h->cfg.layers - 1;
+    const size_t Rl = lastl ? (size_t)n_utts : R;     // the last layer keeps compact rows (frame 0 only)
     if (base == "h0") { *offset_bytes = L.h0; *size_bytes = R * d * e; }
     else if (base == "qkv") { *offset_bytes = L.qkv[l]; *size_bytes = R * 3 * d * e; }
-    else if (base == "o") { *offset_bytes = L.o[l]; *size_bytes = R * d * e; }
-    else if (base == "h1") { *offset_bytes = L.h1[l]; *size_bytes = R * d * e; }
-    else if (base == "f") { *offset_bytes = L.f[l]; *size_bytes = R * (size_t)h->cfg.ffn * e; }
-    else if (base == "h2") { *offset_bytes = L.h2[l]; *size_bytes = R * d * e; }
-    else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
+    else if (base == "o") { *offset_bytes = L.o[l]; *size_bytes = Rl * d * e; }
+    else if (base == "h1") { *offset_bytes = L.h1[l]; *size_bytes = Rl * d * e; }
+    else if (base == "f") { *offset_bytes = L.f[l]; *size_bytes = Rl * (size_t)h->cfg.ffn * e; }
+    else if (base == "h2") { *offset_bytes = L.h2[l]; *size_bytes = Rl * d * e; }
     else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
+    else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
     else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }
     else if (train && base == "dP") { *offset_bytes = L.dP; *size_bytes = R * d * e; }
     else if (train && base == "dM") { *offset_bytes = L.dM; *size_bytes = R * d * e; }

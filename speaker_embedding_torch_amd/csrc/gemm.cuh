@@ -11,7 +11,7 @@
 
 namespace ge2e {
 
-enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD };
+enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_ADD_ROW0 };
 enum { ALOAD_ROW = 0, ALOAD_MEL };
 
 struct GemmArgs {
@@ -23,6 +23,7 @@ struct GemmArgs {
     const void* R; int ldr;      // residual (EPI_LN), addend (EPI_ADD), mask source (EPI_MASK), dH0 (EPI_PRENET_BWD)
     const float* gamma; const float* beta; float* rstd; float eps;   // EPI_LN
     Drop drop;                   // dropout site of this epilogue (thr == 0: inactive)
+    int drow_mul;                // dropout counter row = row * drow_mul (compact t=0 rows of the last layer: T); 0 = 1
     float mask_scale;            // EPI_MASK: gradient scale of kept elements
     const float* pe_t;           // [T, N] transposed positional table (prenet)
     const float* alpha;          // positional_encoding.alpha (device scalar)
@@ -139,7 +140,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     // All global traffic of the epilogue is 16 bytes per lane along rows: the residual / mask / addend tile
     // comes in through LDS, each lane transforms its 4-column groups in place, and the finished tile goes out
     // with full-line stores (the MFMA layout itself would give 32-byte segments per row).
-    constexpr bool NEEDS_R = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
+    constexpr bool NEEDS_R = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD || EPI == EPI_ADD_ROW0);
+    const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
     constexpr int CPRC = BN * (int)sizeof(T) / 16;        // 16-byte chunks per tile row
     constexpr int LDC = BN * (int)sizeof(T) + 16;         // LDS row stride of the staged tile
     constexpr int NCC = BM * CPRC / 256;                  // chunks per thread
@@ -153,6 +155,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
             for (int q = 0; q < 8 && q0 + q < NCC; ++q) {
                 const int id = tid + 256 * (q0 + q), row = id / CPRC, c = id % CPRC, gr = m0 + row;
+                if constexpr (EPI == EPI_ADD_ROW0) {     // addend exists for frame-0 rows only: R is [M / T, N] compact
+                    const int un = gr / p.T;
+                    rr[q] = (gr < p.M && gr == un * p.T) ? *(const u32x4*)(Rg + ((size_t)un * p.ldr + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
+                } else
                 rr[q] = gr < p.M ? *(const u32x4*)(Rg + ((size_t)gr * p.ldr + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
             }
 #pragma unroll
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
                 const f32x4 b4 = *(const f32x4*)(p.bias + col);
                 const f32x4 r4 = load4(crow + lcolb + nt * 16);
                 f32x4 v4 = acc[mt][nt] + b4;
-                drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v4);
+                drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v4);
                 v4 += r4;
                 acc[mt][nt] = v4;
                 sum += v4[0] + v4[1] + v4[2] + v4[3];
@@ -213,20 +219,20 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
                 if constexpr (EPI == EPI_BIAS_RELU_DROP) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v);
+                    drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
                 }
                 if constexpr (EPI == EPI_PRENET) {
                     const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
                     const float al = *p.alpha;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) + al * pe4[r];
-                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, v);
+                    drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
                 }
                 if constexpr (EPI == EPI_PRENET_BWD) {
                     // v = prenet pre-activation (recomputed); staged tile = dL/dh0 -> masked gradient of the pre-activation
                     const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
                     f32x4 d4 = load4(crow + lcolb + nt * 16);
-                    drop_apply4(p.drop, (uint32_t)row * (uint32_t)p.N + (uint32_t)col, d4);
+                    drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, d4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float gv = row < p.M ? d4[r] : 0.0f;
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
                 }
-                if constexpr (EPI == EPI_ADD) v += load4(crow + lcolb + nt * 16);
+                if constexpr (EPI == EPI_ADD || EPI == EPI_ADD_ROW0) v += load4(crow + lcolb + nt * 16);
                 store4(crow + lcolb + nt * 16, v[0], v[1], v[2], v[3]);
             }
         }

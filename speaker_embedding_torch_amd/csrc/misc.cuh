@@ -71,6 +71,7 @@ struct LnBwdArgs {
     float* dgamma; float* dbeta;
     int R;
     Drop drop;
+    int drow_mul;        // dropout counter row = row * drow_mul (0 = 1)
 };
 
 template <typename T>
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
         for (int r = 0; r < 4; ++r) dx[r] = rs * (dxh[r] - s1 - xh[r] * s2);
         store4((T*)p.dpre + (size_t)row * 256 + c0, dx[0], dx[1], dx[2], dx[3]);
         if (p.dmask) {
-            drop_apply4(p.drop, (uint32_t)row * 256u + (uint32_t)c0, dx);
+            drop_apply4(p.drop, (uint32_t)row * (uint32_t)(p.drow_mul > 0 ? p.drow_mul : 1) * 256u + (uint32_t)c0, dx);
             store4((T*)p.dmask + (size_t)row * 256 + c0, dx[0], dx[1], dx[2], dx[3]);
         }
     }
