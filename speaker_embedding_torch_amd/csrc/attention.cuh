@@ -11,7 +11,8 @@ namespace ge2e {
 
 struct AttnArgs {
     const void* qkv;     // [R, 3*D] of T : q | k | v, head h at columns h*64
-    void* o;             // fwd out   [R, D]
+    void* o;             // fwd out   [R, D]   (bwd: the saved forward output, for delta = dO . O)
+    float* lse;          // [R, H] log-sum-exp of the scaled scores: written by fwd when non-null, read by bwd
     const void* dout;    // bwd in    [R, D]
     void* dqkv;          // bwd out   [R, 3*D]
     int T, H, D;
@@ -64,7 +65,7 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
 }
 }  // namespace attn
 
-template <typename T, int KT>
+template <typename T, int KT, int SBE = 1>
 __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
@@ -88,9 +89,9 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
         f32x4 s[NT16];
         float mx = -INFINITY;
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
+        for (int t = 0; t < NT16; ++t) { const int sb_i = t;
             s[t] = attn::tile_dot<T>(Ks, t, qf, i, g);   // S^T[key 16t+4g+r][query qrow]
-            __builtin_amdgcn_sched_barrier(0);   // keep live ranges per tile (VGPR 173 -> 91)
+            if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);   // keep live ranges per tile (VGPR 173 -> 91)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = (16 * t + 4 * g + r) < p.T ? s[t][r] * p.scale : -INFINITY;
@@ -104,11 +105,13 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
-        const float inv = 1.0f / cross4_sum(sum);
+        const float tot = cross4_sum(sum);
+        const float inv = 1.0f / tot;
+        if (p.lse && g == 0 && vq) p.lse[((size_t)n * p.T + qrow) * p.H + h] = mx + logf(tot);
         // dropout counter of P[query][key] = (head_row * T + query) * T4 + key, T4 = T rounded up to 4 (aligned quads)
         const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
+        for (int t = 0; t < NT16; ++t) { const int sb_i = t;
             s[t] *= inv;
             drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t]);
         }
@@ -117,12 +120,12 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) {
+        for (int gi = 0; gi < NG; ++gi) { const int sb_i = gi;
             const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // O^T[d = 16dt+4g+r][query] += V^T[d][keys] * P^T[keys][query]
                 oacc[dt] = mma16<T>(frag_tr<T>(Vs, G::LD, gi * KG, dt * 16, lane), pb, oacc[dt]);
-            __builtin_amdgcn_sched_barrier(0);
+            if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
             T* orow = (T*)p.o + ((size_t)n * p.T + qrow) * p.D + h * 64 + 4 * g;
@@ -132,18 +135,20 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     }
 }
 
-// Backward.  Phase A (wave owns 16 queries; K, V in LDS): recompute P, dP -> row stats (max, 1/sum, delta)
-// to LDS and dQ.  Phase B (wave owns 16 keys; Q, dO in LDS): recompute P and dS from the stats -> dK, dV.
-template <typename T, int KT>
+// Backward.  The forward saved lse = log sum_k exp(score) per (row, head), and delta_i = sum_k P_ik dP_ik equals
+// dO_i . O_i (also with dropout, because O was formed from the dropped P), so no softmax reduction is redone:
+// every 16x16 tile of P and dS is a pure function of its own scores.
+//   Phase A (wave owns 16 queries; K, V in LDS): delta -> LDS, dQ^T += K^T dS^T.
+//   Phase B (wave owns 16 keys;    Q, dO in LDS): dV^T += dO^T Pd, dK^T += Q^T dS.
+template <typename T, int KT, int SBE = 1>
 __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
-    constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
+    constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const bufA = smem;
     unsigned char* const bufB = smem + TP * G::LD;
-    float* const st_m = (float*)(smem + 2 * TP * G::LD);
-    float* const st_l = st_m + TP;
-    float* const st_d = st_l + TP;
+    float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse per query of this head
+    float* const st_d = st_l + TP;                            // delta per query
     const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -152,12 +157,16 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     const unsigned char* kbase = qbase + (size_t)p.D * sizeof(T);
     const unsigned char* vbase = qbase + (size_t)2 * p.D * sizeof(T);
     const unsigned char* dobase = (const unsigned char*)p.dout + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
+    const unsigned char* obase = (const unsigned char*)p.o + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
     T* const dq_out = (T*)p.dqkv + (size_t)n * p.T * 3 * p.D + h * 64;
     const uint32_t hbase = (uint32_t)blockIdx.x * (uint32_t)p.T;
+    const uint32_t T4 = (uint32_t)((p.T + 3) & ~3);
 
     // ---------------------------------------------------------------- phase A
     attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
     attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
+    for (int q = threadIdx.x; q < TP; q += blockDim.x)
+        st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] : 0.0f;
     __syncthreads();
     for (int qt = wave; qt * 16 < p.T; qt += nw) {
         const int qrow = qt * 16 + i;
@@ -165,58 +174,46 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
         u32x4 qf[G::NKG], dof[G::NKG];
         attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
         attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
-        f32x4 s[NT16];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            s[t] = attn::tile_dot<T>(bufA, t, qf, i, g);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = (16 * t + 4 * g + r) < p.T ? s[t][r] * p.scale : -INFINITY;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-        mx = cross4_max(mx);
-        float sum = 0.0f;
-#pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
-        const float inv = 1.0f / cross4_sum(sum);
-        const uint32_t T4 = (uint32_t)((p.T + 3) & ~3);
-        const uint32_t ibase = (hbase + (uint32_t)qrow) * T4;
-        f32x4 dp[NT16];
         float delta = 0.0f;
+        {
+            u32x4 of[G::NKG];
+            attn::load_row_frags<T>(of, obase, ldo, qrow, vq, g);
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            dp[t] = attn::tile_dot<T>(bufB, t, dof, i, g);     // d(P dropped)^T[key][query]
-            __builtin_amdgcn_sched_barrier(0);
-            drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp[t]);
+            for (int k = 0; k < G::NKG; ++k) {
+                const T* a = (const T*)&dof[k];
+                const T* b = (const T*)&of[k];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = s[t][r] * inv;
-                s[t][r] = pr;
-                delta += pr * dp[t][r];
+                for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
             }
         }
         delta = cross4_sum(delta);
-        if (g == 0 && vq) { st_m[qrow] = mx; st_l[qrow] = inv; st_d[qrow] = delta; }
-#pragma unroll
-        for (int t = 0; t < NT16; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[t][r] = s[t][r] * (dp[t][r] - delta) * p.scale;   // dS^T (scaled)
+        if (g == 0 && vq) st_d[qrow] = delta;
+        const float lse = st_l[vq ? qrow : 0];
+        const uint32_t ibase = (hbase + (uint32_t)qrow) * T4;
         f32x4 qacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) qacc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            const u32x4 sb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
+            const int sb_i = gi;
+            f32x4 ds[2];
+#pragma unroll
+            for (int u = 0; u < TPG; ++u) {
+                const int t = gi * TPG + u;
+                const f32x4 sa = attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
+                f32x4 dp = attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
+                drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = (16 * t + 4 * g + r) < p.T ? exp_prec<T>(sa[r] * p.scale - lse) : 0.0f;
+                    ds[u][r] = pr * (dp[r] - delta) * p.scale;
+                }
+            }
+            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // dQ^T[d][query] += K^T[d][keys] * dS^T[keys][query]
                 qacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, qacc[dt]);
-            __builtin_amdgcn_sched_barrier(0);
+            if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
             T* row = dq_out + (size_t)qrow * 3 * p.D + 4 * g;
@@ -240,25 +237,23 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            constexpr int TPG = KG / 16;                 // query tiles per k-group (2 bf16, 1 f32)
+            const int sb_i = gi;
             f32x4 pd[2], ds[2];
 #pragma unroll
             for (int u = 0; u < TPG; ++u) {
                 const int t = gi * TPG + u;
                 const f32x4 sa = attn::tile_dot<T>(bufA, t, kf, i, g);    // S[query 16t+4g+r][key krow]
                 const f32x4 da = attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
-                __builtin_amdgcn_sched_barrier(0);
-                const f32x4 m4 = *(const f32x4*)(st_m + 16 * t + 4 * g);
                 const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
                 const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * t + 4 * g + r;
                     const bool ok = (q < p.T) && vk;
-                    const float pr = ok ? exp_prec<T>(sa[r] * p.scale - m4[r]) * l4[r] : 0.0f;
-                    const uint32_t idx = (hbase + (uint32_t)q) * (uint32_t)((p.T + 3) & ~3) + (uint32_t)krow;
-                    const float dv = ok ? drop_apply(p.drop, idx, da[r]) : 0.0f;
-                    pd[u][r] = drop_apply(p.drop, idx, pr);
+                    const float pr = ok ? exp_prec<T>(sa[r] * p.scale - l4[r]) : 0.0f;
+                    const bool keep = p.drop.thr == 0 || drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr);
+                    const float dv = keep ? da[r] * p.drop.scale : 0.0f;
+                    pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
                     ds[u][r] = ok ? pr * (dv - d4[r]) * p.scale : 0.0f;
                 }
             }
@@ -269,7 +264,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
                 vacc[dt] = mma16<T>(frag_tr<T>(bufB, G::LD, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
                 kacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vk) {
             T* row = dq_out + (size_t)krow * 3 * p.D + 4 * g;
@@ -281,7 +276,6 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
         }
     }
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Last layer: only frame t = 0 of the encoder output is consumed (reference Modules.py:54), so its

@@ -38,6 +38,10 @@ struct ge2e_handle_s {
     int prof_mask = 0;                     // bench.py roofline leg (ge2e_profile_enable)
     std::vector<ProfRec> prof;
     std::vector<hipEvent_t> ev_pool;
+    // backward overlap: weight-gradient GEMMs run on an internal side stream, fenced with events
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fence_pool;    // hipEventDisableTiming events, reused every call
+    int overlap = 1;                       // GE2E_NO_OVERLAP=1 turns the side stream off
 };
 
 namespace {
@@ -85,8 +89,10 @@ struct Layout {
     size_t w_l1[MAX_LAYERS], w_l1T[MAX_LAYERS], w_l2[MAX_LAYERS], w_l2T[MAX_LAYERS];
     size_t wqT = 0, pe_t = 0, h0 = 0;
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
+    size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
+    size_t dP2 = 0, dM2 = 0, c_dP2 = 0, c_dM2 = 0;     // outputs of the norm1 backward (set 2: the side stream still reads set 1)
     // last layer: only frame 0 of its output is consumed, so everything after its K/V projection lives on
     // COMPACT rows (one per utterance): o/h1/f/h2 of that layer and this backward scratch
     size_t c_dH = 0, c_dHb = 0, c_dP = 0, c_dM = 0, c_dF = 0, c_dO = 0, c_dQ0 = 0, c_tmp = 0;
@@ -121,6 +127,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
             L.h1[l] = take(Rl * d * e);     L.rstd1[l] = take(Rl * 4);
             L.f[l] = take(Rl * f * e);      L.h2[l] = take(Rl * d * e);
             L.rstd2[l] = take(Rl * 4);
+            L.lse[l] = l == last ? (size_t)-1 : take(R * (size_t)c.heads * 4);
         }
     } else {        // eval: layers reuse one set of buffers; h2 overwrites the layer input
         const size_t qkv = take(R * 3 * d * e);
@@ -128,8 +135,9 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         if (c.layers > 1) { o = take(R * d * e); h1 = take(R * d * e); ff = take(R * f * e); }
         for (int l = 0; l < last; ++l) {
             L.qkv[l] = qkv; L.o[l] = o; L.h1[l] = h1; L.f[l] = ff; L.h2[l] = L.h0;
-            L.rstd1[l] = L.rstd2[l] = (size_t)-1;
+            L.rstd1[l] = L.rstd2[l] = L.lse[l] = (size_t)-1;
         }
+        L.lse[last] = (size_t)-1;
         L.qkv[last] = qkv; L.o[last] = take((size_t)n * d * e); L.h1[last] = take((size_t)n * d * e);
         L.f[last] = take((size_t)n * f * e); L.h2[last] = take((size_t)n * d * e);
         L.rstd1[last] = L.rstd2[last] = (size_t)-1;
@@ -140,7 +148,9 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     if (train) {
         L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dP = take(R * d * e); L.dM = take(R * d * e);
         L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
+        L.dP2 = take(R * d * e); L.dM2 = take(R * d * e);
         const size_t nn = (size_t)n;
+        L.c_dP2 = take(nn * d * e); L.c_dM2 = take(nn * d * e);
         L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
         L.c_dF = take(nn * f * e); L.c_dO = take(nn * d * e); L.c_dQ0 = take(nn * d * e); L.c_tmp = take(nn * d * e);
     }
@@ -218,22 +228,24 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_ge
 template <typename T, int XLOAD>
 int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     constexpr int RS = 2 * Prec<T>::KG;
-    constexpr int LD = 128 * (int)sizeof(T) + 16;
+    constexpr int LD = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     if (a.N % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: N must be a multiple of 128");
     if (XLOAD == ALOAD_ROW && a.K % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: K must be a multiple of 128");
     const int tn = a.N / 128, tk = (a.K + 127) / 128;
-    int splits = (1024 + tn * tk - 1) / (tn * tk);
+    // row slices: enough blocks for ~2 per CU, few enough that the fp32 partial tiles (one 64 KB atomic flush per
+    // block) stay small next to the operand traffic
+    int splits = (512 + tn * tk - 1) / (tn * tk);
     const int max_splits = (a.R + 4 * RS - 1) / (4 * RS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     int rps = (a.R + splits - 1) / splits;
     rps = (rps + RS - 1) / RS * RS;
     splits = (a.R + rps - 1) / rps;
-    a.rows_per_split = rps;
-    const size_t smem = 4 * (size_t)RS * LD;
+    a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
+    const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
     auto kern = wgrad_kernel<T, XLOAD>;
     ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * a.R * a.N * a.K);
-    GE2E_LAUNCH(h, kern, dim3(tn, tk, splits), dim3(256), smem, st, a);
+    GE2E_LAUNCH(h, kern, dim3(tn * tk * splits), dim3(256), smem, st, a);
     return 0;
 }
 
@@ -252,7 +264,7 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
         auto kern = attn_fwd_kernel<T, KT>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
-        const size_t smem = 2 * (size_t)TP * G::LD + 3 * (size_t)TP * 4;
+        const size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4;
         auto kern = attn_bwd_kernel<T, KT>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     }
@@ -295,6 +307,45 @@ int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_
 }
 
 #define CK(x) do { int _e = (x); if (_e) return _e; } while (0)
+
+// Side-stream fencing for backward: weight-gradient GEMMs only consume tensors the main chain has finished and
+// produce gradients nobody reads before the end of backward, so they run on an internal stream next to the
+// latency-bound dgrad / attention / LayerNorm kernels of the main stream.
+struct SideCtx {
+    ge2e_handle h; hipStream_t main_st; hipStream_t side = nullptr; bool on = false; size_t next = 0; int err = 0;
+    SideCtx(ge2e_handle h_, hipStream_t m) : h(h_), main_st(m) {
+        if (!h->overlap) return;
+        if (!h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return; }
+        side = h->side; on = true;
+    }
+    hipEvent_t ev() {
+        // reuse an event only once its previous record has completed (a host thread running several steps ahead
+        // of the GPU must not re-record an event another stream may still be about to wait on)
+        while (next < h->fence_pool.size() && hipEventQuery(h->fence_pool[next]) != hipSuccess) ++next;
+        if (next == h->fence_pool.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = 1; return nullptr; }
+            h->fence_pool.push_back(e);
+        }
+        return h->fence_pool[next++];
+    }
+    hipStream_t wstream() const { return on ? side : main_st; }
+    void fork() {                           // side waits for everything enqueued on main so far
+        if (!on) return;
+        hipEvent_t e = ev();
+        if (!e || hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) err = 1;
+    }
+    hipEvent_t mark() {                     // event after everything enqueued on side so far
+        if (!on) return nullptr;
+        hipEvent_t e = ev();
+        if (!e || hipEventRecord(e, side) != hipSuccess) { err = 1; return nullptr; }
+        return e;
+    }
+    void wait(hipEvent_t& e) {              // main waits for a side-stream reader before overwriting its input
+        if (on && e && hipStreamWaitEvent(main_st, e, 0) != hipSuccess) err = 1;
+        e = nullptr;
+    }
+};
 
 template <typename T>
 int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
@@ -369,6 +420,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, 
         if (!last) {   // softmax(q k^T / 8) v per (utterance, head)
             AttnArgs a{};
             a.qkv = ws + L.qkv[l]; a.o = ws + L.o[l]; a.T = t; a.H = c.heads; a.D = d;
+            a.lse = train ? (float*)(ws + L.lse[l]) : nullptr;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, false));
@@ -433,6 +485,9 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     };
     hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
     if (e != hipSuccess) return fail_hip(h, e, "zero grads");
+    SideCtx sc(h, st);
+    hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
+    hipEvent_t g_set1 = nullptr, g_set2 = nullptr, g_dF = nullptr, g_dQKV = nullptr;   // last side-stream reader of a buffer
     {
         TailArgs a{};
         a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
@@ -451,7 +506,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
     const size_t esz = L.esz;
     for (int l = c.layers - 1; l >= 0; --l) {
-        if (stop_after >= 0 && c.layers - 1 - l >= stop_after) return 0;
+        if (stop_after >= 0 && c.layers - 1 - l >= stop_after) { hipEvent_t done = sc.mark(); sc.wait(done); return 0; }
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
         // the last layer runs on compact rows (one per utterance, frame 0) until its attention; see forward_impl
         const bool last = l == c.layers - 1;
@@ -460,12 +515,15 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         unsigned char* const b_dHb = ws + (last ? L.c_dHb : L.dHb);
         unsigned char* const b_dP = ws + (last ? L.c_dP : L.dP);
         unsigned char* const b_dM = ws + (last ? L.c_dM : L.dM);
+        unsigned char* const b_dP2 = ws + (last ? L.c_dP2 : L.dP2);   // norm1-backward outputs (set 2)
+        unsigned char* const b_dM2 = ws + (last ? L.c_dM2 : L.dM2);
         unsigned char* const b_dF = ws + (last ? L.c_dF : L.dF);
         unsigned char* const b_dO = ws + (last ? L.c_dO : L.dO);
         const int ln_grid = std::min(2048, (Rl + 3) / 4);
         const Drop d_ff = make_drop(true, c.tf_dropout, seed, step, site_ff(l));
         const Drop d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
         const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
+        sc.wait(g_set1);
         {   // norm2 backward
             LnBwdArgs a{};
             a.dy = b_dH; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
@@ -476,23 +534,27 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
         unsigned char* gm = d_ff.thr ? b_dM : b_dP;
+        sc.wait(g_dF);
         {   // dF = (dG W2) masked by ReLU/dropout of the hidden
             GemmArgs a{};
             a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = b_dF; a.ldc = c.ffn;
             a.M = Rl; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
             CK((gemm128<T, EPI_MASK>(h, st, a)));
         }
+        sc.fork();
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            g_set1 = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
             a.R = Rl; a.N = c.ffn; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            g_dF = sc.mark();
         }
         {   // dH1 = dPre2 + dF W1
             GemmArgs a{};
@@ -500,41 +562,48 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, a)));
         }
+        sc.wait(g_set2);
         {   // norm1 backward
             LnBwdArgs a{};
             a.dy = b_dHb; a.y = ws + L.h1[l]; a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)];
-            a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = b_dP; a.dmask = d_sa.thr ? b_dM : nullptr;
+            a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = b_dP2; a.dmask = d_sa.thr ? b_dM2 : nullptr;
             a.dgamma = G(lp(l, L_N1_W)); a.dbeta = G(lp(l, L_N1_B)); a.R = Rl; a.drop = d_sa; a.drow_mul = rmul;
             auto kern = ln_bwd_kernel<T>;
             ProfScope ps(h, st, GE2E_K_LN_BWD, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        gm = d_sa.thr ? b_dM : b_dP;
+        gm = d_sa.thr ? b_dM2 : b_dP2;
         {   // dO = dA Wo
             GemmArgs a{};
             a.A = gm; a.lda = d; a.W = ws + L.w_outT[l]; a.ldw = d; a.C = b_dO; a.ldc = d;
             a.M = Rl; a.N = d; a.K = d;
             CK((gemm128<T, EPI_NONE>(h, st, a)));
         }
+        sc.fork();
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
             a.R = Rl; a.N = d; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            g_set2 = sc.mark();
         }
+        sc.wait(g_dQKV);
         if (!last) {
             AttnArgs a{};
             a.qkv = ws + L.qkv[l]; a.dout = b_dO; a.dqkv = ws + L.dQKV; a.T = t; a.H = c.heads; a.D = d;
+            a.o = ws + L.o[l]; a.lse = (float*)(ws + L.lse[l]);
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, true));
+            sc.fork();
             WgradArgs w{};
             w.Y = ws + L.dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
             w.R = R; w.N = 3 * d; w.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
+            g_dQKV = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
             g.A = ws + L.dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
-            g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP; g.ldr = d;
+            g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP2; g.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, g)));
         } else {
             AttnQ0Args a{};   // one query per (utterance, head): dK, dV for every frame, dQ for frame 0
@@ -542,24 +611,27 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn_q0<T>(h, st, a, n, true));
+            sc.fork();
             WgradArgs wkv{};  // k | v rows of in_proj_weight from every frame
             wkv.Y = ws + L.dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
             wkv.dW = G(lp(l, L_IN_W)) + (size_t)d * d; wkv.ldw = d; wkv.db = G(lp(l, L_IN_B)) + d;
             wkv.R = R; wkv.N = 2 * d; wkv.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, wkv)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wkv)));
             WgradArgs wq{};   // q rows from frame 0 of every utterance
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, st, wq)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wq)));
+            g_dQKV = sc.mark();
             GemmArgs g0{};    // frame-0 addend: dPre1 + dQ0 Wq   (compact)
             g0.A = ws + L.c_dQ0; g0.lda = d; g0.W = ws + L.w_inT[l]; g0.ldw = 3 * d; g0.C = ws + L.c_tmp; g0.ldc = d;
-            g0.M = n; g0.N = d; g0.K = d; g0.R = b_dP; g0.ldr = d;
+            g0.M = n; g0.N = d; g0.K = d; g0.R = b_dP2; g0.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, g0)));
             GemmArgs g{};     // dH(layer input) = dKV Wkv, plus the compact addend on frame-0 rows
             g.A = ws + L.dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
             g.C = ws + L.dHa; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
             CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
         }
+        if (cb) { hipEvent_t done = sc.mark(); sc.wait(done); }   // this layer's weight gradients are final before the bucket goes out
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
     {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place
@@ -569,12 +641,16 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
         CK((gemm128<T, EPI_PRENET_BWD, ALOAD_MEL>(h, st, a)));
+        sc.fork();
         WgradArgs w{};
         w.Y = ws + L.dHa; w.ldy = d; w.X = mel; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim; w.T = t; w.mel = c.mel_dim;
-        CK((launch_wgrad<T, ALOAD_MEL>(h, st, w)));
+        CK((launch_wgrad<T, ALOAD_MEL>(h, wst, w)));
+        hipEvent_t done = sc.mark();
+        sc.wait(done);                                   // join: the caller's stream owns every gradient again
         bucket(P_PRENET_W, P_ALPHA);
     }
+    if (sc.err) return fail(h, GE2E_EINVAL, "side-stream event fencing failed");
     return 0;
 }
 
@@ -615,12 +691,20 @@ int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
     ge2e_handle h = new (std::nothrow) ge2e_handle_s();
     if (!h) return GE2E_EINVAL;
     h->cfg = *cfg;
+    h->overlap = std::getenv("GE2E_NO_OVERLAP") ? 0 : 1;
     build_params(h);
     *out = h;
     return 0;
 }
 
-int ge2e_destroy(ge2e_handle h) { delete h; return 0; }
+int ge2e_destroy(ge2e_handle h) {
+    if (!h) return 0;
+    for (hipEvent_t e : h->fence_pool) hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->side) hipStreamDestroy(h->side);
+    delete h;
+    return 0;
+}
 
 const char* ge2e_last_error(ge2e_handle h) {
     if (!h) return "null handle";
@@ -773,8 +857,8 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
     else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
     else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
     else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }
-    else if (train && base == "dP") { *offset_bytes = L.dP; *size_bytes = R * d * e; }
-    else if (train && base == "dM") { *offset_bytes = L.dM; *size_bytes = R * d * e; }
+    else if (train && base == "dP") { *offset_bytes = L.dP2; *size_bytes = R * d * e; }
+    else if (train && base == "dM") { *offset_bytes = L.dM2; *size_bytes = R * d * e; }
     else if (train && base == "dO") { *offset_bytes = L.dO; *size_bytes = R * d * e; }
     else if (train && base == "dQKV") { *offset_bytes = L.dQKV; *size_bytes = R * 3 * d * e; }
     else return GE2E_EINVAL;

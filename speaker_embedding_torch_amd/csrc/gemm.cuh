@@ -279,6 +279,7 @@ struct WgradArgs {
     float* db;                  // [N] or null
     int R, N, K;                // K = real width (dW columns written: k < K)
     int rows_per_split;         // multiple of the stage height
+    int tiles_n, tiles_k;       // 128x128 output tiles along N and K
     int T, mel;
 };
 
@@ -287,7 +288,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int KG = Prec<T>::KG;
     constexpr int RS = 2 * KG;                              // rows per stage
     constexpr int ROWB = 128 * (int)sizeof(T);              // 128 columns
-    constexpr int LD = ROWB + 16;
+    // row stride == 32 (mod 256) bytes: the 8 rows x 4 lanes x 8 B of one ds_read_b64_tr_b16 half-wave land on 64
+    // distinct banks (a 16-byte pad leaves 2-way conflicts on every transposed read); fp32 scalar reads want +16
+    constexpr int LD = ROWB + (sizeof(T) == 2 ? 32 : 16);
     constexpr int CPR = ROWB / 16;                          // chunks per row
     constexpr int NCH = RS * CPR / 256;                     // chunks per thread (= 4)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -296,8 +299,13 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int rbeg = blockIdx.z * p.rows_per_split;
+    // 1-D grid: consecutive (remapped) ids share an XCD; the tiles of one row slice are consecutive, so the
+    // slice's Y and X panels are fetched from HBM once per XCD and re-read from its L2 by the other tiles
+    const int L = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = p.tiles_n * p.tiles_k;
+    const int tile = L % ntile, split = L / ntile;
+    const int n0 = (tile % p.tiles_n) * 128, k0 = (tile / p.tiles_n) * 128;
+    const int rbeg = split * p.rows_per_split;
     const int rend = min(p.R, rbeg + p.rows_per_split);
     const int nst = (rend - rbeg + RS - 1) / RS;
 
@@ -351,7 +359,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0, 0, 0, 0};
     float bsum = 0.0f;
-    const bool do_bias = (p.db != nullptr) && blockIdx.y == 0;
+    const bool do_bias = (p.db != nullptr) && k0 == 0;
 
     if (nst > 0) {
         load_stage(0);
@@ -385,17 +393,27 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
     if (nst == 0) return;
+    // flush through LDS so that every atomic wave-instruction adds 256 contiguous bytes of one dW row
+    // (full-rate shape, MI355X_MICROARCH "Global float atomics"); straight from the MFMA layout it would be 4 x 64 B
+    constexpr int LDT = 128 * 4 + 16;
+    float* const Ts = (float*)smem;                        // [128][LDT/4]; the stage buffers are dead (barrier above)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int k = k0 + wn * 64 + nt * 16 + i;
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wm * 64 + mt * 16 + 4 * g + r;
-                if (n < p.N && k < p.K) atomicAdd(p.dW + (size_t)n * p.ldw + k, acc[mt][nt][r]);
-            }
+            for (int r = 0; r < 4; ++r)
+                Ts[(wm * 64 + mt * 16 + 4 * g + r) * (LDT / 4) + wn * 64 + nt * 16 + i] = acc[mt][nt][r];
+    __syncthreads();
+    for (int row = wave; row < 128; row += 4) {
+        const int n = n0 + row;
+        if (n >= p.N) break;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int k = k0 + half * 64 + lane;
+            if (k < p.K) atomicAdd(p.dW + (size_t)n * p.ldw + k, Ts[row * (LDT / 4) + half * 64 + lane]);
         }
+    }
     if (do_bias) {
         const int col = tid & 127;
         if (n0 + col < p.N) atomicAdd(p.db + n0 + col, bsum);
