@@ -29,6 +29,7 @@ sys.path.insert(0, REPO)
 from speaker_embedding_torch_amd import _lib  # noqa: E402
 from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters  # noqa: E402
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
+from speaker_embedding_torch_amd.Optim import FusedClipAdamW  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
@@ -104,8 +105,9 @@ def main():
     criterion = GE2E_Loss().to(dev)
     if world > 1:
         model = apply_gradient_allreduce(model)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,
-                                  betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2), eps=hp.Train.ADAM.Epsilon)
+    optimizer = FusedClipAdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,
+                               betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2), eps=hp.Train.ADAM.Epsilon,
+                               max_norm=hp.Train.Gradient_Norm)      # clip_grad_norm_ + AdamW, as Train.py:154-162
     model.train()
     batches = [synth_mel(S * P, mel, T, 1234 + rank + 1000 * i, dev) for i in range(2)]   # resident in HBM
 
@@ -115,8 +117,6 @@ def main():
         loss = criterion(emb, P)
         optimizer.zero_grad()
         loss.backward()
-        if hp.Train.Gradient_Norm > 0.0:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.Train.Gradient_Norm)
         optimizer.step()
         return loss
 

@@ -104,6 +104,16 @@ int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speaker
 int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
                        float w, float b, const float* d_loss, float* d_emb, void* loss_ws, size_t loss_ws_bytes);
 
+/* clip_grad_norm_(max_norm) followed by one torch.optim.AdamW step (reference Train.py:154-162) over `count`
+ * parameter tensors, fused into two launches.  params/grads/exp_avg/exp_avg_sq: HOST arrays of device pointers
+ * (fp32, numel[i] elements each); norm_scratch: device fp32 scalar (receives the squared total gradient norm);
+ * step: 1-based AdamW step count; max_norm <= 0 disables clipping.  Gradients are left clipped in place, exactly
+ * as clip_grad_norm_ leaves them. */
+int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                         float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int64_t step);
+
 /* Live per-kernel timing for the roofline leg of bench.py.  While a class bit is enabled every launch of that
  * kernel class is bracketed by hipEvents ON THE LAUNCH STREAM; ge2e_profile_read() synchronises those events,
  * returns the summed duration, the summed algorithmic work (FLOPs for the MFMA classes, bytes for the others)

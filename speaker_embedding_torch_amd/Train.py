@@ -30,6 +30,7 @@ from .Datasets import Collater, Dataset, Inference_Collater
 from .distributed import apply_gradient_allreduce, init_distributed, reduce_tensor
 from .Logger import Logger
 from .Modules import GE2E, GE2E_Loss
+from .Optim import FusedClipAdamW
 
 logging.basicConfig(level=logging.INFO, stream=sys.stdout,
                     format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
@@ -92,9 +93,12 @@ class Trainer:
     def Model_Generate(self):
         self.model = GE2E(self.hp, seed=1234 + self.gpu_id).to(self.device)
         self.criterion = GE2E_Loss().to(self.device)
-        self.optimizer = torch.optim.AdamW(
+        # torch.optim.AdamW semantics and state_dict (incl. the default weight_decay 0.01 the reference ends up with,
+        # Train.py:122-127), with clip_grad_norm_(Gradient_Norm) fused into the same two device launches
+        self.optimizer = FusedClipAdamW(
             params=self.model.parameters(), lr=self.hp.Train.Learning_Rate.Initial,
-            betas=(self.hp.Train.ADAM.Beta1, self.hp.Train.ADAM.Beta2), eps=self.hp.Train.ADAM.Epsilon)
+            betas=(self.hp.Train.ADAM.Beta1, self.hp.Train.ADAM.Beta2), eps=self.hp.Train.ADAM.Epsilon,
+            max_norm=self.hp.Train.Gradient_Norm)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(
             optimizer=self.optimizer, gamma=self.hp.Train.Learning_Rate.Decay, last_epoch=-1)
 
@@ -105,9 +109,7 @@ class Trainer:
         loss = self.criterion(embeddings, self.hp.Train.Batch.Train.Pattern_per_Speaker)
         self.optimizer.zero_grad()
         loss.backward()                      # HIP backward; gradient buckets all-reduced as they complete
-        if self.hp.Train.Gradient_Norm > 0.0:
-            torch.nn.utils.clip_grad_norm_(parameters=self.model.parameters(), max_norm=self.hp.Train.Gradient_Norm)
-        self.optimizer.step()
+        self.optimizer.step()                # clip_grad_norm_(Gradient_Norm) + AdamW, fused (Train.py:154-162)
         self.steps += 1
         if self.tqdm is not None:
             self.tqdm.update(1)

@@ -49,6 +49,9 @@ _SIG = {
                                     C.c_void_p, C.c_void_p, C.c_size_t]),
     "ge2e_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "ge2e_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
+                                       C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
     "ge2e_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ge2e_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ge2e_debug_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
@@ -147,6 +150,10 @@ class Handle:
         self.check(self.lib.ge2e_loss_backward(self._h, stream, emb.data_ptr(), speakers, utts, w, b, d_loss.data_ptr(),
                                                d_emb.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size()),
                    "ge2e_loss_backward")
+
+    def clip_adamw_step(self, stream, ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, norm, max_norm, lr, b1, b2, eps, wd, step):
+        self.check(self.lib.ge2e_clip_adamw_step(self._h, stream, len(ptrs_p), ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel,
+                                                 norm.data_ptr(), max_norm, lr, b1, b2, eps, wd, step), "ge2e_clip_adamw_step")
 
     def profile_enable(self, mask):
         self.check(self.lib.ge2e_profile_enable(self._h, mask), "ge2e_profile_enable")

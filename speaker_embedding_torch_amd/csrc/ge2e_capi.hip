@@ -803,6 +803,41 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     return 0;
 }
 
+int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                         float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int64_t step) {
+    if (!h) return GE2E_EINVAL;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !norm_scratch || count <= 0 || step < 1)
+        return fail(h, GE2E_EINVAL, "clip_adamw: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i = 0; i < count; ++i)
+        if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0 || numel[i] > 2147483647LL)
+            return fail(h, GE2E_EINVAL, "clip_adamw: null tensor or bad numel");
+    if (max_norm > 0.0f) {
+        hipError_t e = hipMemsetAsync(norm_scratch, 0, 4, st);
+        if (e != hipSuccess) return fail_hip(h, e, "zero norm");
+    }
+    for (int pass = (max_norm > 0.0f ? 0 : 1); pass < 2; ++pass)          // pass 0: squared norm, pass 1: update
+        for (int b = 0; b < count; b += OPT_MAX_TENSORS) {
+            OptArgs a{};
+            const int cnt = std::min(OPT_MAX_TENSORS, count - b);
+            int chunks = 0;
+            for (int i = 0; i < cnt; ++i) {
+                a.p[i] = params[b + i]; a.g[i] = grads[b + i]; a.m[i] = exp_avg[b + i]; a.v[i] = exp_avg_sq[b + i];
+                a.numel[i] = (int)numel[b + i]; a.chunk0[i] = chunks;
+                chunks += (int)((numel[b + i] + OPT_CHUNK - 1) / OPT_CHUNK);
+            }
+            a.chunk0[cnt] = chunks; a.ntensors = cnt; a.sumsq = norm_scratch; a.max_norm = max_norm;
+            a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+            a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+            a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+            if (pass == 0) GE2E_LAUNCH(h, opt_norm_kernel, dim3(chunks), dim3(256), 0, st, a);
+            else GE2E_LAUNCH(h, opt_adamw_kernel, dim3(chunks), dim3(256), 0, st, a);
+        }
+    return 0;
+}
+
 int ge2e_profile_enable(ge2e_handle h, int class_mask) {
     if (!h) return GE2E_EINVAL;
     std::lock_guard<std::mutex> g(h->mu);

@@ -307,4 +307,62 @@ __global__ void __launch_bounds__(256) loss_bwd_row_kernel(const LossArgs p) {
     p.d_emb[(size_t)irow * 256 + c] = v * p.gscale[0];
 }
 
+// ---------------------------------------------------------------------------------------------
+// clip_grad_norm_(max_norm) + AdamW of reference Train.py:154-162 in two launches over all parameters.
+//   norm kernel : sumsq += sum g^2                               (one atomic per block)
+//   step kernel : coef = min(1, max_norm / (sqrt(sumsq) + 1e-6));  g *= coef (kept, like clip_grad_norm_);
+//                 p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//                 p -= (lr / (1-b1^t)) * m / (sqrt(v) / sqrt(1-b2^t) + eps)          (torch.optim.AdamW)
+// Parameters, gradients and moments are separate tensors: a chunk table maps blocks to (tensor, offset).
+// ---------------------------------------------------------------------------------------------
+constexpr int OPT_MAX_TENSORS = 64;      // per launch (kernel arguments stay under 4 KB); more tensors = more launches
+struct OptArgs {
+    float* p[OPT_MAX_TENSORS]; float* g[OPT_MAX_TENSORS]; float* m[OPT_MAX_TENSORS]; float* v[OPT_MAX_TENSORS];
+    int numel[OPT_MAX_TENSORS];
+    int chunk0[OPT_MAX_TENSORS + 1];     // first 4096-element chunk of each tensor
+    int ntensors;
+    float* sumsq;                        // device scalar, zeroed before the norm kernel
+    float max_norm;                      // <= 0: no clipping
+    float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+};
+constexpr int OPT_CHUNK = 4096;
+
+__device__ __forceinline__ int opt_find(const OptArgs& a, int chunk) {
+    int lo = 0, hi = a.ntensors - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (a.chunk0[mid] <= chunk) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) opt_norm_kernel(const OptArgs a) {
+    __shared__ float red[4];
+    const int t = opt_find(a, blockIdx.x);
+    const int base = (blockIdx.x - a.chunk0[t]) * OPT_CHUNK;
+    const float* g = a.g[t];
+    float acc = 0.0f;
+    for (int q = threadIdx.x; q < OPT_CHUNK; q += 256) {
+        const int e = base + q;
+        if (e < a.numel[t]) { const float x = g[e]; acc += x * x; }
+    }
+    const float s = block256_sum(acc, red);
+    if (threadIdx.x == 0) atomicAdd(a.sumsq, s);
+}
+
+__global__ void __launch_bounds__(256) opt_adamw_kernel(const OptArgs a) {
+    const int t = opt_find(a, blockIdx.x);
+    const int base = (blockIdx.x - a.chunk0[t]) * OPT_CHUNK;
+    float coef = 1.0f;
+    if (a.max_norm > 0.0f) coef = fminf(1.0f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));
+    float* __restrict__ p = a.p[t]; float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
+    const float decay = 1.0f - a.lr * a.weight_decay, step_size = a.lr / a.bc1;
+    for (int q = threadIdx.x; q < OPT_CHUNK; q += 256) {
+        const int e = base + q;
+        if (e >= a.numel[t]) break;
+        const float gr = g[e] * coef;
+        const float mm = a.beta1 * m[e] + (1.0f - a.beta1) * gr;
+        const float vv = a.beta2 * v[e] + (1.0f - a.beta2) * gr * gr;
+        g[e] = gr; m[e] = mm; v[e] = vv;
+        p[e] = p[e] * decay - step_size * (mm / (sqrtf(vv) / a.bc2_sqrt + a.eps));
+    }
+}
+
 }  // namespace ge2e

@@ -162,3 +162,34 @@ def test_two_rank_data_parallel_gradient_mean(tmp_path):
     total = g0.numel()
     assert len(b0) == 5 and sum(c for _, c in b0) == total         # tail, 3 layers, prenet: disjoint cover
     assert b0[0][0] + b0[0][1] == total and b0[-1][0] == 0
+
+
+def test_fused_clip_adamw_matches_torch():
+    """FusedClipAdamW == clip_grad_norm_ + torch.optim.AdamW (reference Train.py:154-162), three steps, incl. state_dict."""
+    from speaker_embedding_torch_amd.Optim import FusedClipAdamW
+    torch.manual_seed(0)
+    shapes = [(256, 80, 1), (256,), (1,), (768, 256), (1024, 256), (5000,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-6)
+    oa = FusedClipAdamW(pa, max_norm=1.0, **kw)
+    ob = torch.optim.AdamW(pb, **kw)
+    for step in range(3):
+        gs = [torch.randn_like(p) * (0.5 if step != 1 else 1e-3) for p in pa]      # step 1: norm below max_norm -> no clipping
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        ob.step()
+        oa.step()
+        assert abs(oa.total_grad_norm().item() - ref_norm.item()) < 1e-4 * ref_norm.item()
+        for p, q in zip(pa, pb):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)           # gradients left clipped in place
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["state"].keys() == sb["state"].keys()
+    for k in sa["state"]:
+        assert set(sa["state"][k]) == {"step", "exp_avg", "exp_avg_sq"}
+        assert float(sa["state"][k]["step"]) == 3.0
+        assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+    ob2 = torch.optim.AdamW(pb, **kw)
+    ob2.load_state_dict(sa)                                                       # torch loads the fused optimizer's state
