@@ -23,6 +23,11 @@ struct AttnArgs {
 template <typename T> __device__ __forceinline__ float exp_prec(float x);
 template <> __device__ __forceinline__ float exp_prec<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float exp_prec<bf16_t>(float x) { return __expf(x); }
+// exp(score * scale - offset) with the constants folded for v_exp_f32 (= 2^x) in bf16 mode: callers pass
+// scale * EXPK and offset * EXPK and call exp_k (one fma + one exp per probability); fp32 mode keeps expf.
+template <typename T> struct ExpK;
+template <> struct ExpK<float> { static constexpr float K = 1.0f; static __device__ __forceinline__ float ex(float x) { return expf(x); } };
+template <> struct ExpK<bf16_t> { static constexpr float K = 1.4426950408889634f; static __device__ __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x); } };
 
 namespace attn {
 template <typename T> struct Geo {
@@ -65,7 +70,7 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
 }
 }  // namespace attn
 
-template <typename T, int KT, int SBE = 1>
+template <typename T, int KT, bool PAD = true, int SBE = 1>
 __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
@@ -83,31 +88,31 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 
     for (int qt = wave; qt * 16 < p.T; qt += nw) {       // wave-uniform loop: EXEC stays full
         const int qrow = qt * 16 + i;
-        const bool vq = qrow < p.T;
+        const bool vq = !PAD || qrow < p.T;                // PAD == false: T is a multiple of 32, no masking anywhere
         u32x4 qf[G::NKG];
         attn::load_row_frags<T>(qf, base, ldq, qrow, vq, g);
         f32x4 s[NT16];
-        float mx = -INFINITY;
+        float mx = -INFINITY;                              // maximum of the RAW scores (scale > 0)
 #pragma unroll
         for (int t = 0; t < NT16; ++t) { const int sb_i = t;
             s[t] = attn::tile_dot<T>(Ks, t, qf, i, g);   // S^T[key 16t+4g+r][query qrow]
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);   // keep live ranges per tile (VGPR 173 -> 91)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = (16 * t + 4 * g + r) < p.T ? s[t][r] * p.scale : -INFINITY;
-                s[t][r] = v;
-                mx = fmaxf(mx, v);
+                if (PAD && (16 * t + 4 * g + r) >= p.T) s[t][r] = -INFINITY;
+                mx = fmaxf(mx, s[t][r]);
             }
         }
         mx = cross4_max(mx);
+        const float ck = p.scale * ExpK<T>::K, mk = mx * ck;
         float sum = 0.0f;
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = exp_prec<T>(s[t][r] - mx); s[t][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = ExpK<T>::ex(s[t][r] * ck - mk); s[t][r] = e; sum += e; }
         const float tot = cross4_sum(sum);
         const float inv = 1.0f / tot;
-        if (p.lse && g == 0 && vq) p.lse[((size_t)n * p.T + qrow) * p.H + h] = mx + logf(tot);
+        if (p.lse && g == 0 && vq) p.lse[((size_t)n * p.T + qrow) * p.H + h] = mx * p.scale + logf(tot);
         // dropout counter of P[query][key] = (head_row * T + query) * T4 + key, T4 = T rounded up to 4 (aligned quads)
         const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
 #pragma unroll
@@ -140,15 +145,20 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 // every 16x16 tile of P and dS is a pure function of its own scores.
 //   Phase A (wave owns 16 queries; K, V in LDS): delta -> LDS, dQ^T += K^T dS^T.
 //   Phase B (wave owns 16 keys;    Q, dO in LDS): dV^T += dO^T Pd, dK^T += Q^T dS.
-template <typename T, int KT, int SBE = 1>
+template <typename T, int KT, bool PAD = true, int SBE = 5>
 __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const bufA = smem;
     unsigned char* const bufB = smem + TP * G::LD;
-    float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse per query of this head
+    float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse (times ExpK) per query of this head
     float* const st_d = st_l + TP;                            // delta per query
+    // bf16 mode hashes the dropout keep bits once (phase A) and hands them to phase B through LDS; fp32 mode (parity
+    // path; its K/V tiles already fill the LDS at 288 frames) re-hashes in phase B instead
+    constexpr bool USE_MASK = sizeof(T) == 2;
+    constexpr int MW = TP / 32;                               // keep-mask words per query row
+    uint32_t* const st_m = (uint32_t*)(st_d + TP);            // [TP][MW] dropout keep bits, filled by phase A
     const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -166,11 +176,14 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
     attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
     for (int q = threadIdx.x; q < TP; q += blockDim.x)
-        st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] : 0.0f;
+        st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
+    const bool dropping = p.drop.thr != 0;
+    if (USE_MASK && dropping) for (int q = threadIdx.x; q < TP * MW; q += blockDim.x) st_m[q] = 0u;
+    const float ck = p.scale * ExpK<T>::K;
     __syncthreads();
     for (int qt = wave; qt * 16 < p.T; qt += nw) {
         const int qrow = qt * 16 + i;
-        const bool vq = qrow < p.T;
+        const bool vq = !PAD || qrow < p.T;
         u32x4 qf[G::NKG], dof[G::NKG];
         attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
         attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
@@ -202,10 +215,16 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
                 const int t = gi * TPG + u;
                 const f32x4 sa = attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
                 f32x4 dp = attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
-                drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp);
+                if (dropping) {      // keep bits are hashed once, here; phase B reads them back from LDS
+                    const uint32_t m = drop_mask4(p.drop, ibase + (uint32_t)(16 * t + 4 * g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = ((m >> r) & 1u) ? dp[r] * p.drop.scale : 0.0f;
+                    if (USE_MASK && vq) atomicOr(st_m + qrow * MW + ((16 * t + 4 * g) >> 5), m << ((16 * t + 4 * g) & 31));
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pr = (16 * t + 4 * g + r) < p.T ? exp_prec<T>(sa[r] * p.scale - lse) : 0.0f;
+                    float pr = ExpK<T>::ex(sa[r] * ck - lse);
+                    if (PAD && (16 * t + 4 * g + r) >= p.T) pr = 0.0f;
                     ds[u][r] = pr * (dp[r] - delta) * p.scale;
                 }
             }
@@ -228,7 +247,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     __syncthreads();
     for (int kt = wave; kt * 16 < p.T; kt += nw) {
         const int krow = kt * 16 + i;
-        const bool vk = krow < p.T;
+        const bool vk = !PAD || krow < p.T;
         u32x4 kf[G::NKG], vf[G::NKG];
         attn::load_row_frags<T>(kf, kbase, ldq, krow, vk, g);
         attn::load_row_frags<T>(vf, vbase, ldq, krow, vk, g);
@@ -249,12 +268,17 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * t + 4 * g + r;
-                    const bool ok = (q < p.T) && vk;
-                    const float pr = ok ? exp_prec<T>(sa[r] * p.scale - l4[r]) : 0.0f;
-                    const bool keep = p.drop.thr == 0 || drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr);
-                    const float dv = keep ? da[r] * p.drop.scale : 0.0f;
-                    pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
-                    ds[u][r] = ok ? pr * (dv - d4[r]) * p.scale : 0.0f;
+                    float pr = ExpK<T>::ex(sa[r] * ck - l4[r]);
+                    if (PAD && !((q < p.T) && vk)) pr = 0.0f;
+                    float dv = da[r];
+                    pd[u][r] = pr;
+                    if (dropping) {
+                        const bool keep = USE_MASK ? (bool)((st_m[q * MW + (krow >> 5)] >> (krow & 31)) & 1u)
+                                                   : drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr);
+                        dv = keep ? dv * p.drop.scale : 0.0f;
+                        pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
+                    }
+                    ds[u][r] = pr * (dv - d4[r]) * p.scale;
                 }
             }
             const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);

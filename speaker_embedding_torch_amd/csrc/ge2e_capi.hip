@@ -51,6 +51,7 @@ int fail(ge2e_handle h, int code, const std::string& msg) {
     return code;
 }
 int fail_hip(ge2e_handle h, hipError_t e, const char* what) {
+    (void)hipGetLastError();       // the error is reported through the return code: do not leave it sticky for later launches
     return fail(h, (int)e, std::string(what) + ": " + hipGetErrorString(e));
 }
 
@@ -249,7 +250,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     return 0;
 }
 
-template <typename T, int KT>
+template <typename T, int KT, bool PAD>
 int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT;
@@ -261,27 +262,28 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
     ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H);
     if (!bwd) {
         const size_t smem = 2 * (size_t)TP * G::LD;
-        auto kern = attn_fwd_kernel<T, KT>;
+        auto kern = attn_fwd_kernel<T, KT, PAD>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
-        const size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4;
-        auto kern = attn_bwd_kernel<T, KT>;
+        const size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 ? (size_t)TP * (TP / 32) * 4 : 0);
+        auto kern = attn_bwd_kernel<T, KT, PAD>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     }
     return 0;
 }
 template <typename T>
 int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
+    const bool pad = a.T % 32 != 0;      // multiples of 32 frames need no key / query masking
     switch ((a.T + 31) / 32) {
-        case 1: return launch_attn_kt<T, 1>(h, st, a, n, bwd);
-        case 2: return launch_attn_kt<T, 2>(h, st, a, n, bwd);
-        case 3: return launch_attn_kt<T, 3>(h, st, a, n, bwd);
-        case 4: return launch_attn_kt<T, 4>(h, st, a, n, bwd);
-        case 5: return launch_attn_kt<T, 5>(h, st, a, n, bwd);
-        case 6: return launch_attn_kt<T, 6>(h, st, a, n, bwd);
-        case 7: return launch_attn_kt<T, 7>(h, st, a, n, bwd);
-        case 8: return launch_attn_kt<T, 8>(h, st, a, n, bwd);
-        case 9: return launch_attn_kt<T, 9>(h, st, a, n, bwd);
+        case 1: return pad ? launch_attn_kt<T, 1, true>(h, st, a, n, bwd) : launch_attn_kt<T, 1, false>(h, st, a, n, bwd);
+        case 2: return pad ? launch_attn_kt<T, 2, true>(h, st, a, n, bwd) : launch_attn_kt<T, 2, false>(h, st, a, n, bwd);
+        case 3: return pad ? launch_attn_kt<T, 3, true>(h, st, a, n, bwd) : launch_attn_kt<T, 3, false>(h, st, a, n, bwd);
+        case 4: return pad ? launch_attn_kt<T, 4, true>(h, st, a, n, bwd) : launch_attn_kt<T, 4, false>(h, st, a, n, bwd);
+        case 5: return pad ? launch_attn_kt<T, 5, true>(h, st, a, n, bwd) : launch_attn_kt<T, 5, false>(h, st, a, n, bwd);
+        case 6: return pad ? launch_attn_kt<T, 6, true>(h, st, a, n, bwd) : launch_attn_kt<T, 6, false>(h, st, a, n, bwd);
+        case 7: return pad ? launch_attn_kt<T, 7, true>(h, st, a, n, bwd) : launch_attn_kt<T, 7, false>(h, st, a, n, bwd);
+        case 8: return pad ? launch_attn_kt<T, 8, true>(h, st, a, n, bwd) : launch_attn_kt<T, 8, false>(h, st, a, n, bwd);
+        case 9: return pad ? launch_attn_kt<T, 9, true>(h, st, a, n, bwd) : launch_attn_kt<T, 9, false>(h, st, a, n, bwd);
         default: return fail(h, GE2E_EUNSUPPORTED, "attention: frames > 288 not instantiated");
     }
 }

@@ -19,8 +19,8 @@ __global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
 }
 template <int SBE> void run(const AttnArgs& a, int n, const char* tag) {
     using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    const size_t sf = 2 * (size_t)TP * G::LD, sb = sf + 2 * TP * 4;
-    auto kf = attn_fwd_kernel<T, KT, SBE>; auto kb = attn_bwd_kernel<T, KT, SBE>;
+    const size_t sf = 2 * (size_t)TP * G::LD, sb = sf + 2 * TP * 4 + TP * (TP / 32) * 4;
+    auto kf = attn_fwd_kernel<T, KT, false, SBE>; auto kb = attn_bwd_kernel<T, KT, false, SBE>;
     CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
     float f = time_kernel([&]() { hipLaunchKernelGGL(kf, dim3(n * 4), dim3(320), sf, 0, a); });
@@ -36,6 +36,6 @@ int main() {
     AttnArgs a{}; a.qkv = qkv; a.o = o; a.dout = dout; a.dqkv = dqkv; a.T = T_; a.H = 4; a.D = D; a.scale = 0.125f;
     a.drop = Drop{12345u, 6553u, 1.1111f};
     float* lse; CHECK(hipMalloc(&lse, R * 4 * 4)); a.lse = lse;
-    run<1>(a, n, "sbe=1"); run<2>(a, n, "sbe=2"); run<5>(a, n, "sbe=5"); run<100>(a, n, "sbe=none");
+    run<1>(a, n, "sbe=1"); run<5>(a, n, "sbe=5");
     return 0;
 }
