@@ -214,7 +214,7 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if (a.K % BK != 0 || a.N % BN != 0 || a.M <= 0)
         return fail(h, GE2E_EUNSUPPORTED, "gemm: N must be a multiple of the tile and K of the k-step");
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
-    const size_t smem = std::max<size_t>(2 * (size_t)(BM + BN) * 128, (size_t)BM * (BN * sizeof(T) + 16));
+    const size_t smem = std::max<size_t>(2 * (size_t)(BM + BN) * 128, EPI == EPI_LN ? (size_t)BM * (BN + 4) * 4 : (size_t)BM * (BN * sizeof(T) + 16));
     auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD>;
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM,
                  2.0 * a.M * a.N * (ALOAD == ALOAD_MEL ? a.mel : a.K));
@@ -224,7 +224,7 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 template <typename T, int EPI, int ALOAD = ALOAD_ROW>
 int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD>(h, st, a); }
 template <typename T>
-int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 128, 256, 32, 256, EPI_LN, ALOAD_ROW>(h, st, a); }
+int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a); }
 
 template <typename T, int XLOAD>
 int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {

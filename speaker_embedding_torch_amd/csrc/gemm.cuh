@@ -140,8 +140,60 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     // All global traffic of the epilogue is 16 bytes per lane along rows: the residual / mask / addend tile
     // comes in through LDS, each lane transforms its 4-column groups in place, and the finished tile goes out
     // with full-line stores (the MFMA layout itself would give 32-byte segments per row).
-    constexpr bool NEEDS_R = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD || EPI == EPI_ADD_ROW0);
+    constexpr bool NEEDS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD || EPI == EPI_ADD_ROW0);
     const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
+    if constexpr (EPI == EPI_LN) {
+        // Row-complete tile (BN == N == 256): park the raw fp32 accumulators in LDS, then every wave finishes whole
+        // rows the way the LayerNorm kernels do -- one row per wave pass, 4 columns per lane, wave-wide reductions --
+        // so bias, residual and the output are all full-row (512 B / 1 KB) coalesced accesses.
+        static_assert(BN == 256, "LayerNorm epilogue needs the whole row in the tile");
+        constexpr int LDF = BN + 4;                        // floats per staged row (16-byte pad)
+        float* const Fs = (float*)smem;                    // main loop ended with a barrier: LDS is free
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                *(f32x4*)(Fs + (wm * WM + mt * 16 + i) * LDF + wn * WN + nt * 16 + 4 * g) = acc[mt][nt];
+        __syncthreads();
+        const uint32_t drm_ = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
+        const int c0 = lane * 4;
+        const f32x4 b4 = *(const f32x4*)(p.bias + c0), g4 = *(const f32x4*)(p.gamma + c0), be4 = *(const f32x4*)(p.beta + c0);
+        const T* const Rm = (const T*)p.R;
+        T* const Cm = (T*)p.C;
+        // 4 independent rows per pass: their loads and the two dependent wave reductions interleave (the chain
+        // LDS -> residual -> mean -> variance of a single row is pure latency)
+        constexpr int RPW = BM / 4;                        // rows per wave
+#pragma unroll 1
+        for (int it = 0; it < RPW; it += 4) {
+            f32x4 v[4];
+            float mean[4], rstd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int lr = wave * RPW + it + u, row = m0 + lr;
+                v[u] = *(const f32x4*)(Fs + lr * LDF + c0) + b4;
+                drop_apply4(p.drop, (uint32_t)row * drm_ * (uint32_t)BN + (uint32_t)c0, v[u]);
+                if (row < p.M) v[u] += load4(Rm + (size_t)row * p.ldr + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) mean[u] = wave_sum(v[u][0] + v[u][1] + v[u][2] + v[u][3]) * (1.0f / (float)BN);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] -= mean[u];
+                rstd[u] = wave_sum(v[u][0] * v[u][0] + v[u][1] * v[u][1] + v[u][2] * v[u][2] + v[u][3] * v[u][3]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = m0 + wave * RPW + it + u;
+                const float rs = 1.0f / sqrtf(rstd[u] * (1.0f / (float)BN) + p.eps);
+                if (row < p.M) {
+                    if (lane == 0 && p.rstd) p.rstd[row] = rs;
+                    store4(Cm + (size_t)row * p.ldc + c0, v[u][0] * rs * g4[0] + be4[0], v[u][1] * rs * g4[1] + be4[1],
+                           v[u][2] * rs * g4[2] + be4[2], v[u][3] * rs * g4[3] + be4[3]);
+                }
+            }
+        }
+        return;
+    }
     constexpr int CPRC = BN * (int)sizeof(T) / 16;        // 16-byte chunks per tile row
     constexpr int LDC = BN * (int)sizeof(T) + 16;         // LDS row stride of the staged tile
     constexpr int NCC = BM * CPRC / 256;                  // chunks per thread
@@ -176,36 +228,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
         const int row = m0 + lrow;
         const int lcolb = wn * WN + 4 * g, colb = n0 + lcolb;
         T* const crow = (T*)(Cs + lrow * LDC);
-        if constexpr (EPI == EPI_LN) {
-            float sum = 0.0f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = colb + nt * 16;
-                const f32x4 b4 = *(const f32x4*)(p.bias + col);
-                const f32x4 r4 = load4(crow + lcolb + nt * 16);
-                f32x4 v4 = acc[mt][nt] + b4;
-                drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v4);
-                v4 += r4;
-                acc[mt][nt] = v4;
-                sum += v4[0] + v4[1] + v4[2] + v4[3];
-            }
-            const float mean = cross4_sum(sum) * (1.0f / (float)BN);
-            float sq = 0.0f;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { const float d = acc[mt][nt][r] - mean; sq += d * d; }
-            const float rstd = 1.0f / sqrtf(cross4_sum(sq) * (1.0f / (float)BN) + p.eps);
-            if (g == 0 && p.rstd && row < p.M) p.rstd[row] = rstd;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = colb + nt * 16;
-                const f32x4 g4 = *(const f32x4*)(p.gamma + col), be4 = *(const f32x4*)(p.beta + col);
-                store4(crow + lcolb + nt * 16,
-                       (acc[mt][nt][0] - mean) * rstd * g4[0] + be4[0], (acc[mt][nt][1] - mean) * rstd * g4[1] + be4[1],
-                       (acc[mt][nt][2] - mean) * rstd * g4[2] + be4[2], (acc[mt][nt][3] - mean) * rstd * g4[3] + be4[3]);
-            }
-        } else {
+        {
             int t = 0;
             if constexpr (EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) t = row < p.M ? row % p.T : 0;
 #pragma unroll
