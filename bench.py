@@ -32,6 +32,7 @@ from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
 from speaker_embedding_torch_amd.Optim import FusedClipAdamW  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+HBM_PEAK_GBS = 8000.0                             # HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
                     "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD}
 
@@ -40,6 +41,19 @@ def synth_mel(n, mel, t, seed, device):
     """x = clamp(-5 + 2 z, log(1e-5), 2): the log-mel range of meldataset.py:51-52,93-94."""
     g = torch.Generator(device=device).manual_seed(seed)
     return (torch.randn(n, mel, t, device=device, generator=g) * 2.0 - 5.0).clamp_(-11.5129, 2.0)
+
+
+def load_pmc_traffic(kernel):
+    """HBM bytes per launch of the class from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json:
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE); None until measured."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json"))):
+        try:
+            best = json.load(open(path)).get(kernel, best)
+        except Exception:
+            pass
+    return best
 
 
 def cpu_baseline(speakers, utts, frames, mel, budget_speakers=4, steps=2):
@@ -148,15 +162,28 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        ms, work, launches = hnd.profile_read(klass)
+        ms, flops, nbytes, launches = hnd.profile_read(klass)
         if launches and ms > 0:
-            achieved = work / (ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": {"gemm": "gemm_nt_kernel<128x128>", "gemm_ln": "gemm_nt_kernel<128x256,LN>",
-                        "wgrad": "wgrad_kernel", "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
-                        "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK[args.precision], 4), "traffic": None,
-                        "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                        "class_ms_per_step": round(ms / args.steps, 3)}
+            tf = flops / (ms * 1e-3) / 1e12
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            ai = flops / max(nbytes, 1.0)                       # algorithmic FLOP per HBM byte of the class
+            ridge = PEAK[args.precision] * 1e12 / (HBM_PEAK_GBS * 1e9)
+            hbm_bound = ai < ridge                              # which roof is lower at this arithmetic intensity
+            roofline = {
+                "bound": "hbm" if hbm_bound else "mfma",
+                "kernel": {"gemm": "gemm_nt_kernel<128x128>", "gemm_ln": "gemm_nt_kernel<64x256,LN>", "wgrad": "wgrad_kernel",
+                           "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
+                "achieved": round(gbs if hbm_bound else tf, 2), "peak": HBM_PEAK_GBS if hbm_bound else PEAK[args.precision],
+                "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / PEAK[args.precision]), 4),
+                "traffic": load_pmc_traffic(args.roofline_kernel),
+                "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
+                "class_ms_per_step": round(ms / args.steps, 3),
+                "algorithmic_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
+                "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / PEAK[args.precision], 4),
+                "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": round(nbytes / launches), "algorithmic_flops_per_launch": round(flops / launches),
+            }
     if rank == 0:
         out = {
             "metric": "utterances/sec (64spk x 15utt, T=160, 80-mel) training step",

@@ -116,8 +116,8 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
 
 /* Live per-kernel timing for the roofline leg of bench.py.  While a class bit is enabled every launch of that
  * kernel class is bracketed by hipEvents ON THE LAUNCH STREAM; ge2e_profile_read() synchronises those events,
- * returns the summed duration, the summed algorithmic work (FLOPs for the MFMA classes, bytes for the others)
- * and the launch count, and resets the class.  Disabled (mask 0) there is no overhead. */
+ * returns the summed duration, the summed algorithmic FLOPs, the summed algorithmic HBM bytes (operands in + tile
+ * out, each counted once per launch) and the launch count, and resets the class.  Disabled (mask 0) there is no overhead. */
 enum {
     GE2E_K_GEMM = 1,       /* 128x128-tile projection GEMMs (prenet, in_proj, FFN1, dgrads)   work = 2*M*N*K   */
     GE2E_K_GEMM_LN = 2,    /* 128x256-tile GEMMs with the residual+LayerNorm epilogue         work = 2*M*N*K   */
@@ -127,7 +127,8 @@ enum {
     GE2E_K_LN_BWD = 32     /* LayerNorm backward                                               work = bytes moved */
 };
 int ge2e_profile_enable(ge2e_handle h, int class_mask);
-int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, int64_t* launches);
+int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, double* total_bytes,
+                      int64_t* launches);
 
 /* Diagnostics: byte offset/size inside the workspace of a named intermediate of the last forward
  * ("h0", "qkv.<l>", "o.<l>", "h1.<l>", "f.<l>", "h2.<l>", and after a backward the scratch of the LAST

@@ -53,7 +53,8 @@ _SIG = {
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
     "ge2e_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
-    "ge2e_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ge2e_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int64)]),
     "ge2e_debug_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ge2e_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int]),
@@ -159,9 +160,10 @@ class Handle:
         self.check(self.lib.ge2e_profile_enable(self._h, mask), "ge2e_profile_enable")
 
     def profile_read(self, klass):
-        ms, work, cnt = C.c_double(), C.c_double(), C.c_int64()
-        self.check(self.lib.ge2e_profile_read(self._h, klass, C.byref(ms), C.byref(work), C.byref(cnt)), "ge2e_profile_read")
-        return ms.value, work.value, cnt.value
+        ms, work, nbytes, cnt = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        self.check(self.lib.ge2e_profile_read(self._h, klass, C.byref(ms), C.byref(work), C.byref(nbytes), C.byref(cnt)),
+                   "ge2e_profile_read")
+        return ms.value, work.value, nbytes.value, cnt.value
 
     def debug_tap(self, name, n, t, train):
         off, size = C.c_size_t(), C.c_size_t()

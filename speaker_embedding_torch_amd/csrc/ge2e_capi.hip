@@ -27,7 +27,7 @@ struct ParamInfo { std::string name; int64_t numel, offset; };
 
 }  // namespace
 
-struct ProfRec { int klass; hipEvent_t start, stop; double work; };
+struct ProfRec { int klass; hipEvent_t start, stop; double work, bytes; };
 
 struct ge2e_handle_s {
     ge2e_config cfg;
@@ -176,13 +176,13 @@ inline int site_ff(int l) { return 4 + 4 * l; }
 // brackets one launch with events on its stream when its class is being profiled
 struct ProfScope {
     ge2e_handle h; hipStream_t st; bool on = false; ProfRec rec{};
-    ProfScope(ge2e_handle h_, hipStream_t st_, int klass, double work) : h(h_), st(st_) {
+    ProfScope(ge2e_handle h_, hipStream_t st_, int klass, double work, double bytes = 0.0) : h(h_), st(st_) {
         if (!(h->prof_mask & klass)) return;
         auto get = [&]() { hipEvent_t e = nullptr;
             if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
             return e; };
         std::lock_guard<std::mutex> g(h->mu);
-        rec.klass = klass; rec.work = work; rec.start = get(); rec.stop = get();
+        rec.klass = klass; rec.work = work; rec.bytes = bytes; rec.start = get(); rec.stop = get();
         on = rec.start && rec.stop;
         if (on) hipEventRecord(rec.start, st);
     }
@@ -216,8 +216,13 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     const size_t smem = std::max<size_t>(2 * (size_t)(BM + BN) * 128, EPI == EPI_LN ? (size_t)BM * (BN + 4) * 4 : (size_t)BM * (BN * sizeof(T) + 16));
     auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD>;
-    ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM,
-                 2.0 * a.M * a.N * (ALOAD == ALOAD_MEL ? a.mel : a.K));
+    constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
+    const double kk = (ALOAD == ALOAD_MEL ? a.mel : a.K);
+    // algorithmic HBM bytes of one launch: activations in (fp32 mel for the prenet) + weights + tile out (+ tile in)
+    const double abytes = (double)a.M * kk * (ALOAD == ALOAD_MEL ? 4.0 : (double)sizeof(T)) + (double)a.N * kk * sizeof(T) +
+                          (double)a.M * a.N * sizeof(T) * (reads_r ? 2.0 : 1.0) +
+                          (EPI == EPI_ADD_ROW0 ? (double)(a.M / std::max(1, a.T)) * a.N * sizeof(T) : 0.0);
+    ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * kk, abytes);
     GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), smem, st, a);
     return 0;
 }
@@ -245,7 +250,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
     const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
     auto kern = wgrad_kernel<T, XLOAD>;
-    ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * a.R * a.N * a.K);
+    ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * a.R * a.N * a.K, (double)a.R * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
     GE2E_LAUNCH(h, kern, dim3(tn * tk * splits), dim3(256), smem, st, a);
     return 0;
 }
@@ -259,7 +264,8 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
     if (nw > 8) nw = 8;
     if (nw < 1) nw = 1;
     const dim3 grid(n * a.H), block(64 * nw);
-    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H);
+    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H,
+                 (double)n * a.T * a.D * sizeof(T) * (bwd ? 8.0 : 4.0));
     if (!bwd) {
         const size_t smem = 2 * (size_t)TP * G::LD;
         auto kern = attn_fwd_kernel<T, KT, PAD>;
@@ -291,7 +297,8 @@ int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bw
 template <typename T>
 int launch_attn_q0(ge2e_handle h, hipStream_t st, const AttnQ0Args& a, int n, bool bwd) {
     if (a.T > 64 * attn::Q0_KPL || a.H > 4) return fail(h, GE2E_EUNSUPPORTED, "q0 attention: frames > 320 or heads > 4");
-    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 10.0 : 4.0) * a.T * 64.0 * n * a.H);
+    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 10.0 : 4.0) * a.T * 64.0 * n * a.H,
+                 (double)n * a.T * a.D * sizeof(T) * (bwd ? 4.0 : 2.0));
     if (bwd) { auto kern = attn_q0_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
     else { auto kern = attn_q0_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
     return 0;
@@ -532,7 +539,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             a.rstd = (const float*)(ws + L.rstd2[l]); a.dpre = b_dP; a.dmask = d_ff.thr ? b_dM : nullptr;
             a.dgamma = G(lp(l, L_N2_W)); a.dbeta = G(lp(l, L_N2_B)); a.R = Rl; a.drop = d_ff; a.drow_mul = rmul;
             auto kern = ln_bwd_kernel<T>;
-            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)Rl * d * L.esz * (d_ff.thr ? 4 : 3));
+            ProfScope ps(h, st, GE2E_K_LN_BWD, 12.0 * Rl * d, (double)Rl * d * L.esz * (d_ff.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
         unsigned char* gm = d_ff.thr ? b_dM : b_dP;
@@ -571,7 +578,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             a.rstd = (const float*)(ws + L.rstd1[l]); a.dpre = b_dP2; a.dmask = d_sa.thr ? b_dM2 : nullptr;
             a.dgamma = G(lp(l, L_N1_W)); a.dbeta = G(lp(l, L_N1_B)); a.R = Rl; a.drop = d_sa; a.drow_mul = rmul;
             auto kern = ln_bwd_kernel<T>;
-            ProfScope ps(h, st, GE2E_K_LN_BWD, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
+            ProfScope ps(h, st, GE2E_K_LN_BWD, 12.0 * Rl * d, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
         gm = d_sa.thr ? b_dM2 : b_dP2;
@@ -847,27 +854,27 @@ int ge2e_profile_enable(ge2e_handle h, int class_mask) {
     return 0;
 }
 
-int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, int64_t* launches) {
-    if (!h || !total_ms || !total_work || !launches) return GE2E_EINVAL;
+int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, double* total_bytes, int64_t* launches) {
+    if (!h || !total_ms || !total_work || !total_bytes || !launches) return GE2E_EINVAL;
     std::vector<ProfRec> mine, rest;
     {
         std::lock_guard<std::mutex> g(h->mu);
         for (auto& r : h->prof) (r.klass == klass ? mine : rest).push_back(r);
         h->prof.swap(rest);
     }
-    double ms = 0.0, work = 0.0;
+    double ms = 0.0, work = 0.0, bytes = 0.0;
     for (auto& r : mine) {
         hipError_t e = hipEventSynchronize(r.stop);
         float t = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, r.start, r.stop);
         if (e != hipSuccess) return fail_hip(h, e, "profile event");
-        ms += t; work += r.work;
+        ms += t; work += r.work; bytes += r.bytes;
     }
     {
         std::lock_guard<std::mutex> g(h->mu);
         for (auto& r : mine) { h->ev_pool.push_back(r.start); h->ev_pool.push_back(r.stop); }
     }
-    *total_ms = ms; *total_work = work; *launches = (int64_t)mine.size();
+    *total_ms = ms; *total_work = work; *total_bytes = bytes; *launches = (int64_t)mine.size();
     return 0;
 }
 
