@@ -31,7 +31,7 @@ struct GemmArgs {
     int T, mel;                  // frames per utterance, real mel dim (ALOAD_MEL / prenet epilogues)
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     constexpr int FRAG = Prec<T>::FRAG;
     constexpr int BK = 128 / (int)sizeof(T);            // 128-byte LDS rows = two k-groups
@@ -41,8 +41,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     static_assert((BM / WM) * WAVES_N == 4, "4 waves");
     static_assert(ALOAD == ALOAD_ROW || BM == 128, "mel loader assumes 128 rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const As = smem;                       // [2][BM][128 B]
-    unsigned char* const Bs = smem + 2 * BM * 128;        // [2][BN][128 B]
+    // NBUF = 2: double-buffered stages (one barrier per k-step, 64 KB -> 2 blocks per CU for the 128x128 tile);
+    // NBUF = 1: single stage (two barriers per k-step, 32 KB -> a third resident block hides the serial phases)
+    unsigned char* const As = smem;                       // [NBUF][BM][128 B]
+    unsigned char* const Bs = smem + NBUF * BM * 128;     // [NBUF][BN][128 B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -114,7 +116,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     store_stage(0);
     __syncthreads();
     for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
+        const int buf = NBUF == 2 ? (ks & 1) : 0;
         if (ks + 1 < nk) load_stage(ks + 1);
         const unsigned char* a = As + buf * BM * 128;
         const unsigned char* b = Bs + buf * BN * 128;
@@ -132,8 +134,13 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
                 for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mma16<T>(bf, af[mt], acc[mt][nt]);
             }
         }
-        if (ks + 1 < nk) store_stage(buf ^ 1);
-        __syncthreads();
+        if constexpr (NBUF == 2) {
+            if (ks + 1 < nk) store_stage(buf ^ 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                                  // everyone is done reading the single stage
+            if (ks + 1 < nk) { store_stage(0); __syncthreads(); }
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -279,7 +286,11 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
         for (int q = 0; q < NCC; ++q) {
             const int id = tid + 256 * q, row = id / CPRC, c = id % CPRC, gr = m0 + row;
+#ifndef GE2E_NO_NT_STORE   // streaming (non-temporal) stores: the tile is not re-read by this kernel; in_proj 152 -> 119 us
+            if (gr < p.M) __builtin_nontemporal_store(*(const u32x4*)(Cs + row * LDC + c * 16), (u32x4*)(Cg + ((size_t)gr * p.ldc + n0) * sizeof(T) + c * 16));
+#else
             if (gr < p.M) *(u32x4*)(Cg + ((size_t)gr * p.ldc + n0) * sizeof(T) + c * 16) = *(const u32x4*)(Cs + row * LDC + c * 16);
+#endif
         }
     }
     if constexpr (EPI == EPI_PRENET_BWD) {

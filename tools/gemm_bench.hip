@@ -59,7 +59,8 @@ int main(int argc, char** argv) {
         };
         switch (s.epi) {
 #define VARIANTS(EPI_)                                                                                        \
-            run(gemm_nt_kernel<T, 128, 128, 64, 64, EPI_, ALOAD_ROW>, 128, 128, std::max<size_t>(2 * 256 * 128, 128 * (128 * sizeof(T) + 16)), "v1 staged epilogue");
+            run(gemm_nt_kernel<T, 128, 128, 64, 64, EPI_, ALOAD_ROW>, 128, 128, std::max<size_t>(2 * 256 * 128, 128 * (128 * sizeof(T) + 16)), "dbuf 64KB"); \
+            run(gemm_nt_kernel<T, 128, 128, 64, 64, EPI_, ALOAD_ROW, 1>, 128, 128, std::max<size_t>(256 * 128, 128 * (128 * sizeof(T) + 16)), "single 35KB");
             case EPI_BIAS: VARIANTS(EPI_BIAS) break;
             case EPI_BIAS_RELU_DROP: VARIANTS(EPI_BIAS_RELU_DROP) break;
             case EPI_MASK: VARIANTS(EPI_MASK) break;
