@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--utts", type=int, default=None)
     ap.add_argument("--frames", type=int, default=160)
     ap.add_argument("--roofline-kernel", default="gemm", choices=sorted(ROOFLINE_CLASSES))
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="infer: BASELINE.json configs[3] style embed-only run (eval forward, --samples slices per utterance)")
+    ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("-hp", "--hyper_parameters", default=os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
@@ -124,6 +127,26 @@ def main():
                                max_norm=hp.Train.Gradient_Norm)      # clip_grad_norm_ + AdamW, as Train.py:154-162
     model.train()
     batches = [synth_mel(S * P, mel, T, 1234 + rank + 1000 * i, dev) for i in range(2)]   # resident in HBM
+    if args.mode == "infer":      # secondary figure (not BASELINE.json's metric): multi-slice d-vector extraction
+        model.eval()
+        n_utt = S * P
+        xs = [synth_mel(n_utt * args.samples, mel, T, 99 + i, dev) for i in range(2)]
+        with torch.no_grad():
+            for i in range(args.warmup):
+                model(xs[i & 1], args.samples)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                e = model(xs[i & 1], args.samples)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print(json.dumps({"metric": "utterances/sec, embed-only (eval forward)", "value": round(n_utt * args.steps / dt, 1),
+                          "unit": "utterances/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16" if args.precision == "bf16" else "f32",
+                          "data": "synthetic", "config": {"workload": f"{n_utt} utt x {args.samples} slices x {T} fr x {mel} mel, "
+                                                                      f"d-vectors [{n_utt}, 256]"},
+                          "unit_norm_err": float((e.norm(dim=1) - 1).abs().max())}), flush=True)
+        return
 
     def train_step(i):
         """Trainer.Train_Step (Train.py:140-168) without the logging-only loss.item() host sync."""
