@@ -200,6 +200,7 @@ class GE2E(torch.nn.Module):
         self._ws = {}
         self._ws_owner = {}
         self._grad_sync = None          # set by distributed.apply_gradient_allreduce
+        self._poison = False            # tests: fill every handed-out workspace with NaN bit patterns first
 
     # -- plumbing ------------------------------------------------------------------------------
     def _handle(self):
@@ -233,6 +234,8 @@ class GE2E(torch.nn.Module):
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             self._ws[key] = ws
         self._ws_owner[key] = weakref.ref(token) if token is not None else None
+        if self._poison:                # any read of a never-written workspace byte then shows up as NaN
+            ws.fill_(0xFF)
         return ws
 
     def workspace_view(self, name, n, t, train=True):

@@ -175,8 +175,10 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     // ---------------------------------------------------------------- phase A
     attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
     attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
-    for (int q = threadIdx.x; q < TP; q += blockDim.x)
+    for (int q = threadIdx.x; q < TP; q += blockDim.x) {
         st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
+        st_d[q] = 0.0f;          // padded queries: phase B multiplies (dP - delta) by P = 0, so delta must be finite
+    }
     const bool dropping = p.drop.thr != 0;
     if (USE_MASK && dropping) for (int q = threadIdx.x; q < TP * MW; q += blockDim.x) st_m[q] = 0u;
     const float ck = p.scale * ExpK<T>::K;
@@ -278,7 +280,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
                         dv = keep ? dv * p.drop.scale : 0.0f;
                         pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
                     }
-                    ds[u][r] = pr * (dv - d4[r]) * p.scale;
+                    ds[u][r] = (PAD && pr == 0.0f) ? 0.0f : pr * (dv - d4[r]) * p.scale;
                 }
             }
             const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);

@@ -317,10 +317,10 @@ struct WgradArgs {
     int T, mel;
 };
 
-template <typename T, int XLOAD>
+template <typename T, int XLOAD, int NS_ = 3, int KGS = 2>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int KG = Prec<T>::KG;
-    constexpr int RS = 2 * KG;                              // rows per stage
+    constexpr int RS = KGS * KG;                            // rows per stage
     constexpr int ROWB = 128 * (int)sizeof(T);              // 128 columns
     // row stride == 32 (mod 256) bytes: the 8 rows x 4 lanes x 8 B of one ds_read_b64_tr_b16 half-wave land on 64
     // distinct banks (a 16-byte pad leaves 2-way conflicts on every transposed read); fp32 scalar reads want +16
@@ -348,8 +348,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         __syncthreads();
     }
 
-    u32x4 ry[NCH], rx[NCH];
-    auto load_stage = [&](int st) {
+    // NS register sets keep the loads of NS row stages in flight (a block streams ~75 stages: latency, not bytes,
+    // bounds a one-stage prefetch)
+    constexpr int NS = NS_;
+    u32x4 rY[NS][NCH], rX[NS][NCH];
+    auto load_stage = [&](int st, u32x4* ry, u32x4* rx) {
         const int r0 = rbeg + st * RS;
         const unsigned char* Y = (const unsigned char*)p.Y;
 #pragma unroll
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
             }
         }
     };
-    auto store_stage = [&](int buf, int st) {
+    auto store_stage = [&](int buf, int st, const u32x4* ry, const u32x4* rx) {
         unsigned char* y = Ys + buf * RS * LD;
         unsigned char* x = Xs + buf * RS * LD;
 #pragma unroll
@@ -395,38 +398,45 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     float bsum = 0.0f;
     const bool do_bias = (p.db != nullptr) && k0 == 0;
 
-    if (nst > 0) {
-        load_stage(0);
-        store_stage(0, 0);
-    }
-    __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        if (st + 1 < nst) load_stage(st + 1);
-        const unsigned char* y = Ys + buf * RS * LD;
-        const unsigned char* x = Xs + buf * RS * LD;
+    if (nst == 0) return;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            u32x4 af[4];
+    for (int s = 0; s < NS; ++s) load_stage(min(s, nst - 1), rY[s], rX[s]);
+    for (int st0 = 0; st0 < nst; st0 += NS) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) af[mt] = frag_tr<T>(y, LD, kg * KG, wm * 64 + mt * 16, lane);
+        for (int s = 0; s < NS; ++s) {
+            const int st = st0 + s;
+            if (st < nst) {                                   // block-uniform
+                const int buf = st & 1;
+                store_stage(buf, st, rY[s], rX[s]);           // waits for this stage's loads only
+                __syncthreads();                              // also: everyone finished reading buf at stage st - 2
+                // UNCONDITIONAL refill (stage index clamped; the tail re-reads the last stage, <= NS of ~75 stages):
+                // a conditional load makes the number of younger loads path-dependent, and hipcc then falls back
+                // from counted s_waitcnt vmcnt(N) to vmcnt(0) at the next use -- which drains the whole ring
+                load_stage(min(st + NS, nst - 1), rY[s], rX[s]);
+                const unsigned char* y = Ys + buf * RS * LD;
+                const unsigned char* x = Xs + buf * RS * LD;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const u32x4 bf = frag_tr<T>(x, LD, kg * KG, wn * 64 + nt * 16, lane);
-                // acc[mt][nt][r] = dW[n0 + wm*64 + mt*16 + 4g + r][k0 + wn*64 + nt*16 + i]
+                for (int kg = 0; kg < KGS; ++kg) {
+                    u32x4 af[4];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mma16<T>(af[mt], bf, acc[mt][nt]);
+                    for (int mt = 0; mt < 4; ++mt) af[mt] = frag_tr<T>(y, LD, kg * KG, wm * 64 + mt * 16, lane);
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const u32x4 bf = frag_tr<T>(x, LD, kg * KG, wn * 64 + nt * 16, lane);
+                        // acc[mt][nt][r] = dW[n0 + wm*64 + mt*16 + 4g + r][k0 + wn*64 + nt*16 + i]
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mma16<T>(af[mt], bf, acc[mt][nt]);
+                    }
+                }
+                if (do_bias) {
+                    const int col = tid & 127, half = tid >> 7;
+#pragma unroll 4
+                    for (int r = half * (RS / 2); r < (half + 1) * (RS / 2); ++r) bsum += to_f32(*(const T*)(y + r * LD + col * sizeof(T)));
+                }
             }
         }
-        if (do_bias) {
-            const int col = tid & 127, half = tid >> 7;
-#pragma unroll 4
-            for (int r = half * (RS / 2); r < (half + 1) * (RS / 2); ++r) bsum += to_f32(*(const T*)(y + r * LD + col * sizeof(T)));
-        }
-        if (st + 1 < nst) store_stage(buf ^ 1, st + 1);
-        __syncthreads();
     }
-    if (nst == 0) return;
+    __syncthreads();
     // flush through LDS so that every atomic wave-instruction adds 256 contiguous bytes of one dW row
     // (full-rate shape, MI355X_MICROARCH "Global float atomics"); straight from the MFMA layout it would be 4 x 64 B
     constexpr int LDT = 128 * 4 + 16;

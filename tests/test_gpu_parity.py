@@ -40,6 +40,7 @@ def mods():
 
 def build(GE2E, precision, p, layers=3, seed=1234):
     m = GE2E(make_hp(p, layers), precision=precision, seed=seed).cuda()
+    m._poison = True          # workspace starts as NaN patterns: reading anything the kernels did not write fails loudly
     params = O.formula_params(layers=layers)
     sd = m.state_dict()
     for k, v in params.items():
@@ -127,6 +128,7 @@ CASES = [  # n, t, P, dropout, tag
     (12, 77, 3, 0.1, 5),       # ragged: T not a multiple of 16, rows not a multiple of the 128-row tile
     (8, 270, 4, 0.1, 4),       # longest trained length of the shipped YAML (Frame_Length.Max)
     (6, 33, 2, 0.25, 6),       # short, heavy dropout
+    (10, 180, 5, 0.1, 7),      # frame count of BASELINE.json configs[4]
 ]
 
 
