@@ -80,6 +80,16 @@ def cpu_baseline(speakers, utts, frames, mel, budget_speakers=4, steps=2):
 
 
 def main():
+    # Contract: rank 0 prints exactly ONE line (the JSON) on stdout.  Libraries chat on fd 1 too (RCCL prints a version
+    # banner at communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON line is written
+    # to the saved, real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -107,9 +117,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the GE2E hot path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("GE2E_BENCH_FORCE_DIST") == "1"   # the override exercises the RCCL path on one GPU
+    if use_dist:
         from speaker_embedding_torch_amd.distributed import apply_gradient_allreduce
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group(backend="nccl", rank=rank, world_size=world)
 
     hp = Load_Hyper_Parameters(args.hyper_parameters)
@@ -120,7 +132,7 @@ def main():
     torch.manual_seed(0)                       # same initial weights on every rank (then broadcast anyway)
     model = GE2E(hp, precision=args.precision, seed=1234 + rank).to(dev)
     criterion = GE2E_Loss().to(dev)
-    if world > 1:
+    if use_dist:
         model = apply_gradient_allreduce(model)
     optimizer = FusedClipAdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,
                                betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2), eps=hp.Train.ADAM.Epsilon,
@@ -140,12 +152,12 @@ def main():
                 e = model(xs[i & 1], args.samples)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-        print(json.dumps({"metric": "utterances/sec, embed-only (eval forward)", "value": round(n_utt * args.steps / dt, 1),
+        emit({"metric": "utterances/sec, embed-only (eval forward)", "value": round(n_utt * args.steps / dt, 1),
                           "unit": "utterances/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16" if args.precision == "bf16" else "f32",
                           "data": "synthetic", "config": {"workload": f"{n_utt} utt x {args.samples} slices x {T} fr x {mel} mel, "
                                                                       f"d-vectors [{n_utt}, 256]"},
-                          "unit_norm_err": float((e.norm(dim=1) - 1).abs().max())}), flush=True)
+              "unit_norm_err": float((e.norm(dim=1) - 1).abs().max())})
         return
 
     def train_step(i):
@@ -158,7 +170,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
+        if use_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +187,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     hnd.profile_enable(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = tt.item()
@@ -223,8 +235,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, P, T, mel)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        emit(out)
+    if use_dist:
         torch.distributed.destroy_process_group()
 
 
