@@ -89,6 +89,7 @@ struct Layout {
     size_t w_prenet = 0, w_in[MAX_LAYERS], w_inT[MAX_LAYERS], w_out[MAX_LAYERS], w_outT[MAX_LAYERS];
     size_t w_l1[MAX_LAYERS], w_l1T[MAX_LAYERS], w_l2[MAX_LAYERS], w_l2T[MAX_LAYERS];
     size_t wqT = 0, pe_t = 0, h0 = 0;
+    size_t xt = 0;               // packed mel: [R][KP] of T (row-major copy of the channels-first fp32 input)
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
@@ -104,8 +105,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     (void)samples_max;
     Layout L;
     L.esz = c.precision == GE2E_PREC_BF16 ? 2 : 4;
-    const int BK = 128 / (int)L.esz;
-    L.KP = (c.mel_dim + BK - 1) / BK * BK;
+    L.KP = 128;                  // mel_dim <= 128, padded to one 128-column operand tile
     L.R = n * t;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
@@ -119,6 +119,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     }
     L.wqT = take(d * d * 4);
     L.pe_t = take((size_t)t * d * 4);
+    L.xt = take(R * (size_t)L.KP * e);
     L.h0 = take(R * d * e);
     const int last = c.layers - 1;
     if (train) {
@@ -217,9 +218,9 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     const size_t smem = std::max<size_t>(NBUF * (size_t)(BM + BN) * 128, EPI == EPI_LN ? (size_t)BM * (BN + 4) * 4 : (size_t)BM * (BN * sizeof(T) + 16));
     auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD, NBUF>;
     constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
-    const double kk = (ALOAD == ALOAD_MEL ? a.mel : a.K);
+    const double kk = a.K;
     // algorithmic HBM bytes of one launch: activations in (fp32 mel for the prenet) + weights + tile out (+ tile in)
-    const double abytes = (double)a.M * kk * (ALOAD == ALOAD_MEL ? 4.0 : (double)sizeof(T)) + (double)a.N * kk * sizeof(T) +
+    const double abytes = (double)a.M * kk * (double)sizeof(T) + (double)a.N * kk * sizeof(T) +
                           (double)a.M * a.N * sizeof(T) * (reads_r ? 2.0 : 1.0) +
                           (EPI == EPI_ADD_ROW0 ? (double)(a.M / std::max(1, a.T)) * a.N * sizeof(T) : 0.0);
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * kk, abytes);
@@ -241,7 +242,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     constexpr int RS = 2 * Prec<T>::KG;
     constexpr int LD = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     if (a.N % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: N must be a multiple of 128");
-    if (XLOAD == ALOAD_ROW && a.K % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: K must be a multiple of 128");
+    if (XLOAD == ALOAD_ROW && a.ldx % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: the X operand must be stored in whole 128-column tiles");
     const int tn = a.N / 128, tk = (a.K + 127) / 128;
     // row slices: enough blocks for ~2 per CU, few enough that the fp32 partial tiles (one 64 KB atomic flush per
     // block) stay small next to the operand traffic
@@ -398,14 +399,19 @@ int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, 
         GE2E_LAUNCH(h, transpose_f32_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
                     P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
     }
+    // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
+    {
+        auto kern = mel_pack_kernel<T>;
+        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
+    }
     // ---- prenet + ReLU + positional encoding (+ dropout)
     {
         GemmArgs a{};
-        a.A = mel; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.h0; a.ldc = d;
+        a.A = ws + L.xt; a.lda = L.KP; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.h0; a.ldc = d;
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(train, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.alpha = P[P_ALPHA]; a.T = t; a.mel = c.mel_dim;
-        CK((gemm128<T, EPI_PRENET, ALOAD_MEL>(h, st, a)));
+        CK((gemm128<T, EPI_PRENET>(h, st, a)));
     }
     for (int l = 0; l < c.layers; ++l) {
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
@@ -650,16 +656,16 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     }
     {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place
         GemmArgs a{};
-        a.A = mel; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.dHa; a.ldc = d; a.R = ws + L.dHa; a.ldr = d;
+        a.A = ws + L.xt; a.lda = L.KP; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.dHa; a.ldc = d; a.R = ws + L.dHa; a.ldr = d;
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
-        CK((gemm128<T, EPI_PRENET_BWD, ALOAD_MEL>(h, st, a)));
+        CK((gemm128<T, EPI_PRENET_BWD>(h, st, a)));
         sc.fork();
-        WgradArgs w{};
-        w.Y = ws + L.dHa; w.ldy = d; w.X = mel; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
-        w.R = R; w.N = d; w.K = c.mel_dim; w.T = t; w.mel = c.mel_dim;
-        CK((launch_wgrad<T, ALOAD_MEL>(h, wst, w)));
+        WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
+        w.Y = ws + L.dHa; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
+        w.R = R; w.N = d; w.K = c.mel_dim;
+        CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
         hipEvent_t done = sc.mark();
         sc.wait(done);                                   // join: the caller's stream owns every gradient again
         bucket(P_PRENET_W, P_ALPHA);

@@ -12,10 +12,10 @@
 namespace ge2e {
 
 enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_ADD_ROW0 };
-enum { ALOAD_ROW = 0, ALOAD_MEL };
+enum { ALOAD_ROW = 0 };     // operand rows are read row-major (the mel batch is packed to rows first: mel_pack_kernel)
 
 struct GemmArgs {
-    const void* A; int lda;      // [M, K] of T (ALOAD_ROW)  |  mel fp32 [n, mel, T] (ALOAD_MEL)
+    const void* A; int lda;      // [M, K] of T
     const void* W; int ldw;      // [N, K] of T
     void* C; int ldc;            // [M, N] of T
     int M, N, K;                 // K = padded reduction length (multiple of 128 / sizeof(T))
@@ -28,18 +28,16 @@ struct GemmArgs {
     const float* pe_t;           // [T, N] transposed positional table (prenet)
     const float* alpha;          // positional_encoding.alpha (device scalar)
     float* dalpha;               // EPI_PRENET_BWD: scalar accumulator
-    int T, mel;                  // frames per utterance, real mel dim (ALOAD_MEL / prenet epilogues)
+    int T, mel;                  // frames per utterance (prenet epilogues: row -> frame), real mel dim
 };
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
-    constexpr int FRAG = Prec<T>::FRAG;
     constexpr int BK = 128 / (int)sizeof(T);            // 128-byte LDS rows = two k-groups
     constexpr int WAVES_N = BN / WN;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int NA = BM / 32, NB = BN / 32;            // 16-byte chunks per thread and stage
     static_assert((BM / WM) * WAVES_N == 4, "4 waves");
-    static_assert(ALOAD == ALOAD_ROW || BM == 128, "mel loader assumes 128 rows");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // NBUF = 2: double-buffered stages (one barrier per k-step, 64 KB -> 2 blocks per CU for the 128x128 tile);
     // NBUF = 1: single stage (two barriers per k-step, 32 KB -> a third resident block hides the serial phases)
@@ -57,29 +55,12 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     u32x4 ra[NA], rb[NB];
     auto load_stage = [&](int ks) {
         const int k0 = ks * BK;
-        if constexpr (ALOAD == ALOAD_ROW) {
+        {
             const unsigned char* A = (const unsigned char*)p.A;
 #pragma unroll
             for (int q = 0; q < NA; ++q) {
                 const int id = tid + 256 * q, row = id >> 3, c = id & 7, gr = m0 + row;
                 ra[q] = gr < p.M ? *(const u32x4*)(A + ((size_t)gr * p.lda + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
-            }
-        } else {
-            // A[r][k] = mel[n][k][t], r = n*T + t: lanes run along t (contiguous in memory)
-            const float* X = (const float*)p.A;
-            const int row = tid & 127, gr = m0 + row;
-            const int n = gr / p.T, t = gr - n * p.T;
-#pragma unroll
-            for (int q = 0; q < NA; ++q) {
-                const int c = (tid >> 7) + 2 * q;
-                float v[FRAG];
-#pragma unroll
-                for (int j = 0; j < FRAG; ++j) {
-                    const int k = k0 + c * FRAG + j;
-                    v[j] = (gr < p.M && k < p.mel) ? X[((size_t)n * p.mel + k) * p.T + t] : 0.0f;
-                }
-                if constexpr (sizeof(T) == 4) ra[q] = u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
-                else ra[q] = u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4 % FRAG], v[5 % FRAG]), pack_bf16x2(v[6 % FRAG], v[7 % FRAG])};
             }
         }
         const unsigned char* W = (const unsigned char*)p.W;
@@ -94,10 +75,8 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
         unsigned char* b = Bs + buf * BN * 128;
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            int row, c;
-            if constexpr (ALOAD == ALOAD_ROW) { const int id = tid + 256 * q; row = id >> 3; c = id & 7; }
-            else { row = tid & 127; c = (tid >> 7) + 2 * q; }
-            *(u32x4*)(a + swz_off<128>(row, c)) = ra[q];
+            const int id = tid + 256 * q;
+            *(u32x4*)(a + swz_off<128>(id >> 3, id & 7)) = ra[q];
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -304,11 +283,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 // ---------------------------------------------------------------------------------------------
 // weight gradient: dW[n][k] += sum_r Y[r][n] * X[r][k] over this block's slice of rows.
 // Both operands are read TRANSPOSED from plain padded LDS tiles ([row][128 cols]).
-// XLOAD_MEL: X[r][k] = mel[n][k][t] (prenet), k < mel, zero beyond.
 // ---------------------------------------------------------------------------------------------
 struct WgradArgs {
     const void* Y; int ldy;     // [R, N] of T
-    const void* X; int ldx;     // [R, K] of T   |  mel fp32
+    const void* X; int ldx;     // [R, ldx] of T, whole 128-column tiles (K may be smaller: prenet K = mel, ldx = 128)
     float* dW; int ldw;         // [N, ldw] fp32 accumulate (atomics)
     float* db;                  // [N] or null
     int R, N, K;                // K = real width (dW columns written: k < K)
@@ -343,11 +321,6 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     const int rend = min(p.R, rbeg + p.rows_per_split);
     const int nst = (rend - rbeg + RS - 1) / RS;
 
-    if constexpr (XLOAD == ALOAD_MEL) {     // columns >= mel are never written by the loader: zero once
-        for (int q = tid; q < 2 * RS * LD / 16; q += 256) *(u32x4*)(Xs + q * 16) = u32x4{0, 0, 0, 0};
-        __syncthreads();
-    }
-
     // NS register sets keep the loads of NS row stages in flight (a block streams ~75 stages: latency, not bytes,
     // bounds a one-stage prefetch)
     constexpr int NS = NS_;
@@ -360,13 +333,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
             const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
             ry[q] = gr < rend ? *(const u32x4*)(Y + ((size_t)gr * p.ldy + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
         }
-        if constexpr (XLOAD == ALOAD_ROW) {
-            const unsigned char* X = (const unsigned char*)p.X;
+        const unsigned char* X = (const unsigned char*)p.X;
 #pragma unroll
-            for (int q = 0; q < NCH; ++q) {
-                const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
-                rx[q] = gr < rend ? *(const u32x4*)(X + ((size_t)gr * p.ldx + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
-            }
+        for (int q = 0; q < NCH; ++q) {
+            const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
+            rx[q] = gr < rend ? *(const u32x4*)(X + ((size_t)gr * p.ldx + k0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
         }
     };
     auto store_stage = [&](int buf, int st, const u32x4* ry, const u32x4* rx) {
@@ -376,17 +347,7 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         for (int q = 0; q < NCH; ++q) {
             const int id = tid + 256 * q, row = id / CPR, c = id % CPR;
             *(u32x4*)(y + row * LD + c * 16) = ry[q];
-            if constexpr (XLOAD == ALOAD_ROW) *(u32x4*)(x + row * LD + c * 16) = rx[q];
-        }
-        if constexpr (XLOAD == ALOAD_MEL) {   // small operand (mel <= 128 columns): global -> LDS directly, lanes along t
-            const float* X = (const float*)p.X;
-            const int r0 = rbeg + st * RS;
-            for (int id = tid; id < RS * p.mel; id += 256) {
-                const int row = id % RS, m = id / RS, gr = r0 + row;
-                const int n = gr / p.T, t = gr - n * p.T;
-                const float v = gr < rend ? X[((size_t)n * p.mel + m) * p.T + t] : 0.0f;
-                *(T*)(x + row * LD + m * sizeof(T)) = from_f32<T>(v);
-            }
+            *(u32x4*)(x + row * LD + c * 16) = rx[q];
         }
     };
 
