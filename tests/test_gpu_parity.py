@@ -185,6 +185,25 @@ def test_bf16_train_step_vs_oracle(mods, n, t, P, p, tag):
         assert cos > 0.98 and rel_l2(g, r) < 0.25, (name, cos)
 
 
+@pytest.mark.parametrize("layers", [1, 2])
+def test_fp32_other_layer_counts(mods, layers):
+    """Num_Layers is a hyper-parameter: the frame-0-only treatment of the LAST layer must hold for any depth."""
+    GE2E, GE2E_Loss = mods
+    m, params, pe = build(GE2E, "fp32", 0.1, layers=layers)
+    m.train()
+    x_np = O.formula_mel(11, 8, 80, 96, logmel=True)
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, pe=pe)
+    loss_ref, lc = O.loss_forward(emb_ref, 4)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    emb = m(torch.from_numpy(x_np).cuda())
+    loss = GE2E_Loss().cuda()(emb, 4)
+    loss.backward()
+    assert rel_l2(emb.detach().cpu().numpy(), emb_ref) < 1e-4 and abs(loss.item() - float(loss_ref)) < 1e-5
+    tol = 2e-3 if _relu_margin_ok(c) else 0.2
+    for name, prm in m.named_parameters():
+        assert rel_l2(prm.grad.cpu().numpy(), grads_ref[name]) < tol, name
+
+
 def test_multislice_inference_fp32_and_bf16(mods):
     """config 4 shape family: `samples` overlapping slices averaged BEFORE projection (Modules.py:55)."""
     GE2E, _ = mods
