@@ -14,6 +14,7 @@
 
 #include "attention.cuh"
 #include "gemm.cuh"
+#include "gemm_ws.cuh"
 #include "misc.cuh"
 
 using namespace ge2e;
@@ -227,15 +228,50 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), smem, st, a);
     return 0;
 }
+// Short-K bf16 products at full height run on the weight-stationary streaming kernel (gemm_ws.cuh); the fp32 parity
+// path and other K keep the tiled kernel.  The choice must not depend on M: a row's result is then independent of the
+// batch it sits in (the two kernels round LayerNorm statistics differently).
+template <typename T, int EPI>
+constexpr bool ws_epilogue() {
+    return sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_MASK || EPI == EPI_LN);
+}
+inline bool ws_shape(const GemmArgs& a) {
+    static const bool off = getenv("GE2E_NO_WS_GEMM") != nullptr;
+    return !off && a.K == 256 && a.N % 256 == 0 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0;
+}
+template <int EPI>
+int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
+    constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK);
+    if (EPI == EPI_LN && a.N != 256) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: the LayerNorm epilogue needs N == 256");
+    if (reads_r && a.ldr % 8 != 0) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: the addend rows must be 16-byte aligned");
+    const int cg = a.N / 256, ntiles = (a.M + 15) / 16;
+    int parts = (512 / cg) / 8 * 8;                       // two resident blocks per CU
+    if (parts > (ntiles + 7) / 8 * 8) parts = (ntiles + 7) / 8 * 8;
+    if (parts < 8) parts = 8;
+    const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0));
+    ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
+    auto kern = gemm_ws_kernel<EPI, 256>;
+    GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_smem<EPI, 256>()), st, a, parts, ntiles);
+    return 0;
+}
+
 template <typename T, int EPI, int ALOAD = ALOAD_ROW>
 int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
+    if constexpr (ws_epilogue<T, EPI>() && ALOAD == ALOAD_ROW) {
+        if (ws_shape(a)) return launch_gemm_ws<EPI>(h, st, a);
+    }
     // the VALU-heavy ReLU + dropout epilogue gains from a third resident block (single LDS stage: 35 KB), measured
     // 179 -> 144 us for FFN1; the other epilogues measure the same either way and keep the one-barrier double buffer
     constexpr int NBUF = (EPI == EPI_BIAS_RELU_DROP) ? 1 : 2;
     return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD, NBUF>(h, st, a);
 }
 template <typename T>
-int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) { return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a); }
+int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
+    if constexpr (ws_epilogue<T, EPI_LN>()) {
+        if (ws_shape(a)) return launch_gemm_ws<EPI_LN>(h, st, a);
+    }
+    return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a);
+}
 
 template <typename T, int XLOAD>
 int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {

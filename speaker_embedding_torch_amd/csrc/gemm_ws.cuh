@@ -1,0 +1,228 @@
+// Weight-stationary streaming projection GEMM for the short-K shapes (K = 256: in_proj, FFN1, dF, dO; bf16 mode).
+//
+//   C[M, N] = epilogue(A[M, K] . W[N, K]^T)
+//
+// With K = 256 these products are streaming kernels (150 FLOP per HBM byte, under the ridge): what bounds them is
+// how many bytes a CU keeps in flight, not MFMA.  The tiled kernel in gemm.cuh re-stages a 64 KB W tile and a 64 KB
+// A tile per 128x128 output tile (W through L2 1200 times), one k-step in flight.  Here instead
+//   * a block owns 256 output columns for its whole life and keeps their weights in REGISTERS as MFMA fragments
+//     (wave w: columns 64w..64w+63, 4 n-tiles x 8 k-groups x 16 B = 128 VGPRs): W is read once per block;
+//   * the block is persistent over 16-row tiles of A (8 KB each) that arrive by LDS-DMA (global_load_lds, 16 B per
+//     lane) into a 4-slot ring, three tiles ahead, behind counted s_waitcnt vmcnt(N) + one raw s_barrier per tile;
+//     loads never touch a VGPR and are never waited for together with the output stores;
+//   * the epilogue is wave-private: each wave turns its 16x64 accumulator slab into 128-byte row segments through
+//     a 2 KB LDS stage (no block barrier) and streams them out with non-temporal stores; the mask / addend tile of
+//     the MASK / ADD epilogues arrives by LDS-DMA as well, into a wave-private ring.
+// LDS images are lane-linear (the DMA writes base + lane*16), so the XOR swizzle is applied to the SOURCE address
+// and again on the fragment reads (guide rule: both sides or neither).
+#pragma once
+#include "gemm.cuh"
+
+namespace ge2e {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_cvoid_t;
+
+__device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+constexpr int WS_NSTG = 4;     // ring slots
+constexpr int WS_D = 3;        // tiles in flight ahead of the one being consumed
+
+template <int EPI, int K_>
+constexpr size_t gemm_ws_smem() {
+    constexpr bool HAS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_LN);
+    return (size_t)WS_NSTG * 16 * K_ * 2 + (HAS_R ? (size_t)4 * WS_NSTG * 2048 : 0) + 4 * 2048 + (EPI == EPI_LN ? 3 * 1024 + 2 * 4 * 16 * 8 : 0);
+}
+
+// grid = 8 * (N / 256) * (parts / 8) blocks; `parts` (multiple of 8) row partitions, `ntiles` = ceil(M / 16)
+template <int EPI, int K_>
+__global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const int parts, const int ntiles) {
+    using T = bf16_t;
+    constexpr int KGN = K_ / 32;                 // k-groups
+    constexpr int ROWB = K_ * 2;                 // bytes per A row
+    constexpr int CPR = ROWB / 16;               // 16-byte chunks per A row (32 / 16)
+    constexpr int RPI = 64 / CPR;                // A rows per DMA instruction (2 / 4)
+    constexpr int NA = 4 / RPI;                  // A DMA instructions per wave and tile (4 rows per wave)
+    constexpr bool HAS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_LN);
+    constexpr int NR = HAS_R ? 2 : 0;            // R DMA instructions per wave and tile (16 rows x 128 B)
+    constexpr int ATILE = 16 * ROWB;
+    constexpr int D = WS_D, NSTG = WS_NSTG;
+    static_assert(ROWB % 256 == 0, "K must be a multiple of 128");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;                                         // [NSTG][16][ROWB]
+    unsigned char* const Rs = smem + NSTG * ATILE;                          // [4][NSTG][2048]
+    unsigned char* const Os = Rs + (HAS_R ? 4 * NSTG * 2048 : 0);           // [4][2048]
+    float* const Ls = (float*)(Os + 4 * 2048);                              // EPI_LN: bias, gamma, beta [3][256]
+    float* const Xs = Ls + 3 * 256;                                         // EPI_LN: [2][4 waves][16 rows] (mean, M2)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    // block -> (column group, row partition): the column groups of one partition are neighbours on one XCD
+    const int CG = p.N / 256;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cg = slot % CG, part = (slot / CG) * 8 + xcd;
+    const int n0 = cg * 256 + wave * 64;
+    const int my = part < ntiles ? (ntiles - part + parts - 1) / parts : 0;
+    if (my == 0) return;
+
+    // ---- stationary operand: this wave's 64 weight rows as MFMA fragments
+    u32x4 wf[4][KGN];
+    f32x4 b4[4];
+    {
+        const unsigned char* W = (const unsigned char*)p.W;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int kg = 0; kg < KGN; ++kg)
+                wf[nt][kg] = *(const u32x4*)(W + ((size_t)(n0 + nt * 16 + i) * p.ldw + kg * 32 + g * 8) * 2);
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP) b4[nt] = *(const f32x4*)(p.bias + n0 + nt * 16 + 4 * g);
+            else b4[nt] = f32x4{0, 0, 0, 0};
+        }
+        if constexpr (EPI == EPI_LN) {          // N == 256: the block holds whole rows; per-column constants live in LDS
+            Ls[tid] = p.bias[tid]; Ls[256 + tid] = p.gamma[tid]; Ls[512 + tid] = p.beta[tid];
+            __syncthreads();                     // no DMA is in flight yet: an ordinary barrier
+        }
+        // retire these ordinary loads before the first DMA: the compiler's own waits stay out of the loop
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int kg = 0; kg < KGN; ++kg) asm volatile("" : "+v"(wf[nt][kg]));
+            asm volatile("" : "+v"(b4[nt]));
+        }
+    }
+
+    const unsigned char* const Ag = (const unsigned char*)p.A;
+    const unsigned char* const Rg = (const unsigned char*)p.R;
+    const int last_row = p.M - 1;
+    // DMA of the j-th tile of this block into ring slot j % NSTG (j past the end re-fetches the last tile: the
+    // per-iteration instruction counts stay fixed, which is what the counted waits rely on)
+    auto issue = [&](int j) {
+        const int jj = j < my ? j : my - 1;
+        const int r0 = (part + jj * parts) * 16, s = j & (NSTG - 1);
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int r = 4 * wave + q * RPI + lane / CPR, pos = lane % CPR;
+            const int c = pos ^ (r & 15);
+            int gr = r0 + r; gr = gr < last_row ? gr : last_row;
+            glds16(Ag + (size_t)gr * p.lda * 2 + c * 16, As + s * ATILE + (4 * wave + q * RPI) * ROWB);
+        }
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = q * 8 + (lane >> 3), pos = lane & 7;
+                const int c = pos ^ ((r >> 1) & 7);
+                int gr = r0 + r; gr = gr < last_row ? gr : last_row;
+                glds16(Rg + ((size_t)gr * p.ldr + n0) * 2 + c * 16, Rs + (wave * NSTG + s) * 2048 + q * 1024);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(j);
+
+    constexpr int PER = NA + NR;                 // DMA instructions per tile
+    unsigned char* const Ow = Os + wave * 2048;
+    T* const Cg = (T*)p.C;
+    const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
+
+#pragma unroll 1
+    for (int t = 0; t < my; ++t) {
+        // tile t has landed once at most (D-1) younger tiles' DMAs and the stores issued since are outstanding
+        if (t >= D) wait_vmcnt<(D - 1) * PER + 2 * D>();
+        else if (t == 0) wait_vmcnt<(D - 1) * PER>();
+        else if (t == 1) wait_vmcnt<(D - 1) * PER + 2>();
+        else wait_vmcnt<(D - 1) * PER + 4>();
+        __builtin_amdgcn_s_barrier();             // everyone's pieces of tile t are in; slot of tile t-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t + D);
+
+        const int s = t & (NSTG - 1);
+        const unsigned char* const a = As + s * ATILE;
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < KGN; ++kg) {
+            const u32x4 af = lds16(a + swz_off<ROWB>(i, kg * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = mma16<T>(wf[nt][kg], af, acc[nt]);   // acc[nt][r] = C[row i][n0 + 16nt + 4g + r]
+        }
+        const int r0 = (part + t * parts) * 16;
+        const int row = r0 + i;
+        if constexpr (EPI == EPI_LN) {
+            // v = LN(residual + drop(acc + bias)) over the 256 columns of a row, which the four waves hold 64 each:
+            // every wave reduces its slab to (mean, M2) per row, one LDS exchange combines them (Chan's formula)
+            const unsigned char* const rsl = Rs + (wave * NSTG + s) * 2048;
+            f32x4 v[4];
+            float sm = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int lc = wave * 64 + nt * 16 + 4 * g;
+                const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
+                v[nt] = acc[nt] + *(const f32x4*)(Ls + lc);
+                drop_apply4(p.drop, (uint32_t)row * drm * 256u + (uint32_t)lc, v[nt]);
+                v[nt] += load4((const T*)(rsl + so));
+                sm += (v[nt][0] + v[nt][1]) + (v[nt][2] + v[nt][3]);
+            }
+            const float mw = cross4_sum(sm) * (1.0f / 64.0f);
+            float qw = 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = v[nt][r] - mw; qw += d * d; }
+            qw = cross4_sum(qw);
+            float* const xs = Xs + (t & 1) * 128;
+            if (g == 0) { xs[(wave * 16 + i) * 2] = mw; xs[(wave * 16 + i) * 2 + 1] = qw; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            float mean = 0.0f, m2 = 0.0f, mws[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { mws[w] = xs[(w * 16 + i) * 2]; mean += mws[w]; m2 += xs[(w * 16 + i) * 2 + 1]; }
+            mean *= 0.25f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) m2 += 64.0f * (mws[w] - mean) * (mws[w] - mean);
+            const float rs = 1.0f / sqrtf(m2 * (1.0f / 256.0f) + p.eps);
+            if (p.rstd && g == 0 && (i >> 2) == wave && row < p.M) p.rstd[row] = rs;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int lc = wave * 64 + nt * 16 + 4 * g;
+                const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
+                const f32x4 ga = *(const f32x4*)(Ls + 256 + lc), be = *(const f32x4*)(Ls + 512 + lc);
+                store4((T*)(Ow + so), (v[nt][0] - mean) * rs * ga[0] + be[0], (v[nt][1] - mean) * rs * ga[1] + be[1],
+                       (v[nt][2] - mean) * rs * ga[2] + be[2], (v[nt][3] - mean) * rs * ga[3] + be[3]);
+            }
+        } else
+        // ---- wave-private epilogue: 16 rows x 64 columns
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[nt] + b4[nt];
+            const int col = n0 + nt * 16 + 4 * g;
+            // staged 16 x 128 B slab, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); this lane: chunk 2nt + (g >> 1), half g & 1
+            const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
+            if constexpr (EPI == EPI_BIAS_RELU_DROP) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
+            }
+            if constexpr (EPI == EPI_MASK) {
+                const f32x4 m4 = load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
+            }
+            if constexpr (EPI == EPI_ADD) v += load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
+            store4((T*)(Ow + so), v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = q * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 o = lds16(Ow + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            if (r0 + r < p.M) __builtin_nontemporal_store(o, (u32x4*)((unsigned char*)Cg + ((size_t)(r0 + r) * p.ldc + n0) * 2 + c * 16));
+        }
+    }
+}
+
+}  // namespace ge2e

@@ -5,6 +5,7 @@
 #include <vector>
 #include <algorithm>
 #include "gemm.cuh"
+#include "gemm_ws.cuh"
 using namespace ge2e;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -29,12 +30,35 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed) {
         p[i] = (((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f) * 0.1f;
 }
 
+__global__ void count_diff(const uint32_t* a, const uint32_t* b, size_t n, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) c += a[i] != b[i];
+    if (c) atomicAdd(out, c);
+}
+
+template <int EPI>
+void run_ws(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, double flops, double bytes, int parts) {
+    auto kern = gemm_ws_kernel<EPI, 256>;
+    const size_t smem = gemm_ws_smem<EPI, 256>();
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    a.C = C2;
+    const int ntiles = (M + 15) / 16, CG = a.N / 256;
+    const int grid = CG * parts;
+    CHECK(hipMemset(C2, 0, (size_t)M * a.N * 2));
+    float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, 0, a, parts, ntiles); });
+    unsigned long long* d; CHECK(hipMalloc(&d, 8)); CHECK(hipMemset(d, 0, 8));
+    count_diff<<<2048, 256>>>((const uint32_t*)Cref, (const uint32_t*)C2, (size_t)M * a.N / 2, d);
+    unsigned long long h = 0; CHECK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost)); CHECK(hipFree(d));
+    char tag[64]; snprintf(tag, sizeof tag, "WS parts=%d", parts);
+    printf("%-26s %-22s %8.1f us  %7.1f TF/s  %6.2f TB/s(min-bytes)  mismatching words: %llu\n", name, tag, ms * 1e3, flops / ms / 1e9, bytes / ms / 1e9, h);
+}
+
 int main(int argc, char** argv) {
     const int M = 153600;
     using T = bf16_t;
-    T *A, *W, *C, *R; float* bias; float *gamma, *beta, *rstd;
+    T *A, *W, *C, *R, *C2; float* bias; float *gamma, *beta, *rstd;
     CHECK(hipMalloc(&A, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&W, (size_t)1024 * 1024 * 2));
-    CHECK(hipMalloc(&C, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&R, (size_t)M * 1024 * 2));
+    CHECK(hipMalloc(&C, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&C2, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&R, (size_t)M * 1024 * 2));
     CHECK(hipMalloc(&bias, 4096)); CHECK(hipMalloc(&gamma, 4096)); CHECK(hipMalloc(&beta, 4096)); CHECK(hipMalloc(&rstd, (size_t)M * 4));
     fill_bf16<<<2048, 256>>>(A, (size_t)M * 1024, 1); fill_bf16<<<2048, 256>>>(W, (size_t)1024 * 1024, 2);
     fill_bf16<<<2048, 256>>>(R, (size_t)M * 1024, 3); fill_f32<<<4, 256>>>(bias, 1024, 4);
@@ -67,6 +91,18 @@ int main(int argc, char** argv) {
             case EPI_ADD: VARIANTS(EPI_ADD) break;
             case EPI_NONE: VARIANTS(EPI_NONE) break;
         }
+        if (s.K == 256) {
+            for (int tot : {256, 512, 768}) {
+                const int CG = s.N / 256;
+                int parts = (tot / CG) / 8 * 8; if (parts < 8) parts = 8;
+                switch (s.epi) {
+                    case EPI_BIAS: run_ws<EPI_BIAS>(s.name, a, C, C2, M, flops, bytes, parts); break;
+                    case EPI_BIAS_RELU_DROP: run_ws<EPI_BIAS_RELU_DROP>(s.name, a, C, C2, M, flops, bytes, parts); break;
+                    case EPI_MASK: run_ws<EPI_MASK>(s.name, a, C, C2, M, flops, bytes, parts); break;
+                    case EPI_NONE: run_ws<EPI_NONE>(s.name, a, C, C2, M, flops, bytes, parts); break;
+                }
+            }
+        }
     }
     {   // LN-epilogue GEMMs
         for (int K : {256, 1024}) {
@@ -80,6 +116,8 @@ int main(int argc, char** argv) {
             float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(256), smem, 0, a); });
             printf("LN gemm N256 K%-4d          %-22s %8.1f us  %7.1f TF/s  %6.2f TB/s\n", K, "v2 64x256 row-epi", ms * 1e3,
                    2.0 * M * 256 * K / ms / 1e9, 2.0 * ((double)M * K + 2.0 * M * 256) / ms / 1e9);
+            if (K == 256) for (int parts : {256, 512, 768})
+                run_ws<EPI_LN>("LN gemm N256 K256", a, C, C2, M, 2.0 * M * 256 * K, 2.0 * ((double)M * K + 2.0 * M * 256), parts);
         }
     }
     return 0;
