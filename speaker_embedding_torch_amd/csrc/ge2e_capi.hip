@@ -15,6 +15,7 @@
 #include "attention.cuh"
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
+#include "gemm_kl.cuh"
 #include "misc.cuh"
 
 using namespace ge2e;
@@ -43,6 +44,7 @@ struct ge2e_handle_s {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fence_pool;    // hipEventDisableTiming events, reused every call
     int overlap = 1;                       // GE2E_NO_OVERLAP=1 turns the side stream off
+    int num_cus = 0;                       // of the current device, queried at the first persistent launch
 };
 
 namespace {
@@ -269,6 +271,23 @@ template <typename T>
 int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI_LN>()) {
         if (ws_shape(a)) return launch_gemm_ws<EPI_LN>(h, st, a);
+        // FFN2 + LayerNorm (K = 1024): persistent stage-stream kernel, one 512-thread block per CU (gemm_kl.cuh).  It needs a
+        // whole CU's LDS, so it is used where nothing shares the machine (the forward chain), not beside the weight gradients.
+        static const bool kl_off = getenv("GE2E_NO_KL_GEMM") != nullptr;
+        if (!kl_off && a.K == 1024 && a.N == 256 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && a.ldr % 8 == 0) {
+            const int ntiles = (a.M + 127) / 128;
+            if (h->num_cus <= 0) {
+                int dev = 0, n = 0;
+                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                h->num_cus = n;
+            }
+            const int grid = std::min(h->num_cus, ntiles);
+            const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + 2.0 * (double)a.M * a.N);
+            ProfScope ps(h, st, GE2E_K_GEMM_LN, 2.0 * a.M * a.N * (double)a.K, abytes);
+            auto kern = gemm_kl_kernel<EPI_LN, 1024>;
+            GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), (gemm_kl_smem<EPI_LN>()), st, a, ntiles);
+            return 0;
+        }
     }
     return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a);
 }

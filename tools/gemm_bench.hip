@@ -6,6 +6,7 @@
 #include <algorithm>
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
+#include "gemm_kl.cuh"
 using namespace ge2e;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -53,6 +54,23 @@ void run_ws(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, doubl
     printf("%-26s %-22s %8.1f us  %7.1f TF/s  %6.2f TB/s(min-bytes)  mismatching words: %llu\n", name, tag, ms * 1e3, flops / ms / 1e9, bytes / ms / 1e9, h);
 }
 
+template <int EPI, int K_, int ABL = 0>
+void run_kl(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, double flops, double bytes, int grid_cap) {
+    auto kern = gemm_kl_kernel<EPI, K_, ABL>;
+    const size_t smem = gemm_kl_smem<EPI>();
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    a.C = C2;
+    const int ntiles = (M + 127) / 128;
+    const int grid = std::min(grid_cap, ntiles);
+    CHECK(hipMemset(C2, 0, (size_t)M * a.N * 2));
+    float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, 0, a, ntiles); });
+    unsigned long long* d; CHECK(hipMalloc(&d, 8)); CHECK(hipMemset(d, 0, 8));
+    count_diff<<<2048, 256>>>((const uint32_t*)Cref, (const uint32_t*)C2, (size_t)M * a.N / 2, d);
+    unsigned long long h = 0; CHECK(hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost)); CHECK(hipFree(d));
+    char tag[64]; snprintf(tag, sizeof tag, "KL grid=%d abl=%d", grid, ABL);
+    printf("%-26s %-22s %8.1f us  %7.1f TF/s  %6.2f TB/s(min-bytes)  mismatching words: %llu\n", name, tag, ms * 1e3, flops / ms / 1e9, bytes / ms / 1e9, h);
+}
+
 int main(int argc, char** argv) {
     const int M = 153600;
     using T = bf16_t;
@@ -91,8 +109,10 @@ int main(int argc, char** argv) {
             case EPI_ADD: VARIANTS(EPI_ADD) break;
             case EPI_NONE: VARIANTS(EPI_NONE) break;
         }
+        if (s.epi == EPI_ADD && s.K == 1024) { run_kl<EPI_ADD, 1024>(s.name, a, C, C2, M, flops, bytes, 256); run_kl<EPI_ADD, 1024, 1>(s.name, a, C, C2, M, flops, bytes, 256); run_kl<EPI_ADD, 1024, 3>(s.name, a, C, C2, M, flops, bytes, 256); run_kl<EPI_ADD, 1024, 5>(s.name, a, C, C2, M, flops, bytes, 256); run_kl<EPI_ADD, 1024, 2>(s.name, a, C, C2, M, flops, bytes, 256); }
+        if (s.epi == EPI_ADD && s.K == 768) run_kl<EPI_ADD, 768>(s.name, a, C, C2, M, flops, bytes, 256);
         if (s.K == 256) {
-            for (int tot : {256, 512, 768}) {
+            for (int tot : {512}) {
                 const int CG = s.N / 256;
                 int parts = (tot / CG) / 8 * 8; if (parts < 8) parts = 8;
                 switch (s.epi) {
@@ -116,7 +136,8 @@ int main(int argc, char** argv) {
             float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3((M + 63) / 64), dim3(256), smem, 0, a); });
             printf("LN gemm N256 K%-4d          %-22s %8.1f us  %7.1f TF/s  %6.2f TB/s\n", K, "v2 64x256 row-epi", ms * 1e3,
                    2.0 * M * 256 * K / ms / 1e9, 2.0 * ((double)M * K + 2.0 * M * 256) / ms / 1e9);
-            if (K == 256) for (int parts : {256, 512, 768})
+            if (K == 1024) run_kl<EPI_LN, 1024>("LN gemm N256 K1024", a, C, C2, M, 2.0 * M * 256 * K, 2.0 * ((double)M * K + 2.0 * M * 256), 256);
+            if (K == 256) for (int parts : {512})
                 run_ws<EPI_LN>("LN gemm N256 K256", a, C, C2, M, 2.0 * M * 256 * K, 2.0 * ((double)M * K + 2.0 * M * 256), parts);
         }
     }
