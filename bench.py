@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-every", type=int, default=4, help="profile the roofline kernel class on every N-th timed step")
     ap.add_argument("-hp", "--hyper_parameters", default=os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
     args = ap.parse_args()
 
@@ -178,11 +179,17 @@ def main():
         train_step(i)
     hnd = model._handle()
     klass = ROOFLINE_CLASSES[args.roofline_kernel]
-    if not args.no_roofline:
-        hnd.profile_enable(klass)
+    # The per-launch hipEvents of the roofline leg break the back-to-back queueing of ~44 GEMM launches per step
+    # (measured: +0.25 ms on a 4.5 ms step), so only every `--roofline-every`-th step of the timed region carries them:
+    # still live launches of the timed region, a few percent of perturbation instead of 5.5 %.
+    every = max(1, args.roofline_every)
+    profiled_steps = 0
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        sampled = (not args.no_roofline) and (i % every == 0)
+        hnd.profile_enable(klass if sampled else 0)
+        profiled_steps += int(sampled)
         loss = train_step(i)
     fence()
     dt = time.perf_counter() - t0
@@ -206,14 +213,14 @@ def main():
             hbm_bound = ai < ridge                              # which roof is lower at this arithmetic intensity
             roofline = {
                 "bound": "hbm" if hbm_bound else "mfma",
-                "kernel": {"gemm": "gemm_nt_kernel<128x128>", "gemm_ln": "gemm_nt_kernel<64x256,LN>", "wgrad": "wgrad_kernel",
+                "kernel": {"gemm": "projection GEMM class: gemm_ws_kernel (K=256) + gemm_nt_kernel<128x128>", "gemm_ln": "LayerNorm GEMMs: gemm_ws_kernel<LN> + gemm_kl_kernel<LN>", "wgrad": "wgrad_kernel",
                            "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
                 "achieved": round(gbs if hbm_bound else tf, 2), "peak": HBM_PEAK_GBS if hbm_bound else PEAK[args.precision],
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / PEAK[args.precision]), 4),
                 "traffic": load_pmc_traffic(args.roofline_kernel),
                 "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
-                "class_ms_per_step": round(ms / args.steps, 3),
+                "class_ms_per_step": round(ms / max(profiled_steps, 1), 3), "profiled_steps": profiled_steps,
                 "algorithmic_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),
                 "mfma_tflops": round(tf, 2), "mfma_frac": round(tf / PEAK[args.precision], 4),
                 "hbm_gbs": round(gbs, 1), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),

@@ -235,7 +235,9 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 // batch it sits in (the two kernels round LayerNorm statistics differently).
 template <typename T, int EPI>
 constexpr bool ws_epilogue() {
-    return sizeof(T) == 2 && (EPI == EPI_NONE || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_MASK || EPI == EPI_LN);
+    // not EPI_NONE (dO = dA.Wo, backward only): no faster alone (31 vs 33 us), and its 512 persistent blocks cannot share a CU's
+    // LDS with a weight-gradient kernel still running on the side stream -- measured 163 us when that happens
+    return sizeof(T) == 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_MASK || EPI == EPI_LN);
 }
 inline bool ws_shape(const GemmArgs& a) {
     static const bool off = getenv("GE2E_NO_WS_GEMM") != nullptr;

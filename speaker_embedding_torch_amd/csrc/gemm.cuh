@@ -326,7 +326,11 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
     constexpr int NS = NS_;
     u32x4 rY[NS][NCH], rX[NS][NCH];
     auto load_stage = [&](int st, u32x4* ry, u32x4* rx) {
+#ifdef GE2E_WGRAD_ABL
+        const int r0 = (GE2E_WGRAD_ABL & 2) ? 0 : rbeg + st * RS;
+#else
         const int r0 = rbeg + st * RS;
+#endif
         const unsigned char* Y = (const unsigned char*)p.Y;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
@@ -376,6 +380,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                 load_stage(min(st + NS, nst - 1), rY[s], rX[s]);
                 const unsigned char* y = Ys + buf * RS * LD;
                 const unsigned char* x = Xs + buf * RS * LD;
+#ifdef GE2E_WGRAD_ABL
+                if constexpr ((GE2E_WGRAD_ABL & 1) == 0)
+#endif
 #pragma unroll
                 for (int kg = 0; kg < KGS; ++kg) {
                     u32x4 af[4];
@@ -398,6 +405,9 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         }
     }
     __syncthreads();
+#ifdef GE2E_WGRAD_ABL
+    if constexpr (GE2E_WGRAD_ABL & 4) { if (p.R > 0) return; }
+#endif
     // flush through LDS so that every atomic wave-instruction adds 256 contiguous bytes of one dW row
     // (full-rate shape, MI355X_MICROARCH "Global float atomics"); straight from the MFMA layout it would be 4 x 64 B
     constexpr int LDT = 128 * 4 + 16;

@@ -1,38 +1,68 @@
-// Standalone micro-benchmark of the weight-gradient kernel at the real shapes (development tool).
+// Standalone micro-benchmark of the weight-gradient kernels at the real shapes (development tool).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I speaker_embedding_torch_amd/csrc -I tools tools/wgrad_bench.hip -o tools/wgrad_bench
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
+#include <vector>
 #include <algorithm>
 #include "gemm.cuh"
+#include "experimental/wgrad256.cuh"   // measured negative result in-situ, kept for the record
 using namespace ge2e;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+__global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = (bf16_t)(((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f);
+}
 int main() {
     using T = bf16_t; const int R = 153600;
-    T *Y, *X; float *dW, *db;
-    CHECK(hipMalloc(&Y, (size_t)R * 1024 * 2)); CHECK(hipMalloc(&X, (size_t)R * 1024 * 2)); CHECK(hipMalloc(&dW, 1024 * 1024 * 4)); CHECK(hipMalloc(&db, 4096));
-    CHECK(hipMemset(Y, 0x3c, (size_t)R * 1024 * 2)); CHECK(hipMemset(X, 0x3c, (size_t)R * 1024 * 2)); CHECK(hipMemset(dW, 0, 1024 * 1024 * 4)); CHECK(hipMemset(db, 0, 4096));
+    T *Y, *X; float *dW, *dW2, *db, *db2;
+    CHECK(hipMalloc(&Y, (size_t)R * 1024 * 2)); CHECK(hipMalloc(&X, (size_t)R * 1024 * 2));
+    CHECK(hipMalloc(&dW, 1024 * 1024 * 4)); CHECK(hipMalloc(&dW2, 1024 * 1024 * 4)); CHECK(hipMalloc(&db, 4096)); CHECK(hipMalloc(&db2, 4096));
+    fill_bf16<<<2048, 256>>>(Y, (size_t)R * 1024, 1); fill_bf16<<<2048, 256>>>(X, (size_t)R * 1024, 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    struct S { const char* name; int N, K; } shapes[] = {{"l1 N1024 K256", 1024, 256}, {"in N768 K256", 768, 256}, {"out N256 K256", 256, 256}};
-    auto run = [&](auto kern, int RS, const char* tag, int target_blocks) {
-        const int LD = 256 + 32;
-        const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
-        CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        for (auto& sh : shapes) {
+    struct S { const char* name; int N, K; } shapes[] = {{"l1 N1024 K256", 1024, 256}, {"l2 N256 K1024", 256, 1024}, {"in N768 K256", 768, 256}, {"out N256 K256", 256, 256}};
+    for (auto& sh : shapes) {
+        const double fl = 2.0 * R * sh.N * sh.K, by = 2.0 * R * (sh.N + sh.K);
+        float ms;
+        {   // 128 x 128 tiles
+            constexpr int RS = 64; const int LD = 256 + 32;
+            auto kern = wgrad_kernel<T, ALOAD_ROW, 3, 2>;
+            const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
+            CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             WgradArgs a{}; a.Y = Y; a.ldy = sh.N; a.X = X; a.ldx = sh.K; a.dW = dW; a.ldw = sh.K; a.db = db; a.R = R; a.N = sh.N; a.K = sh.K;
             const int tn = sh.N / 128, tk = sh.K / 128;
-            int splits = (target_blocks + tn * tk - 1) / (tn * tk); int rps = (R + splits - 1) / splits; rps = (rps + RS - 1) / RS * RS; splits = (R + rps - 1) / rps;
+            int splits = (512 + tn * tk - 1) / (tn * tk); int rps = (R + splits - 1) / splits; rps = (rps + RS - 1) / RS * RS; splits = (R + rps - 1) / rps;
             a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
-            float ms;
             for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(256), smem, 0, a);
             hipEventRecord(e0); for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(256), smem, 0, a); hipEventRecord(e1); hipEventSynchronize(e1);
             hipEventElapsedTime(&ms, e0, e1); CHECK(hipGetLastError());
-            const double fl = 2.0 * R * sh.N * sh.K, by = 2.0 * R * (sh.N + sh.K);
-            printf("%-22s %-14s blocks %4d  %7.1f us  %6.1f TF/s  %5.2f TB/s\n", tag, sh.name, tn * tk * splits, ms * 100, fl / (ms / 10 * 1e-3) / 1e12, by / (ms / 10 * 1e-3) / 1e12);
+            printf("%-16s %-14s blocks %4d  %7.1f us  %6.1f TF/s  %5.2f TB/s\n", "128x128 ns3", sh.name, tn * tk * splits, ms * 100, fl / (ms / 10 * 1e-3) / 1e12, by / (ms / 10 * 1e-3) / 1e12);
+            CHECK(hipMemset(dW, 0, 1024 * 1024 * 4)); CHECK(hipMemset(db, 0, 4096));
+            hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(256), smem, 0, a);
         }
-    };
-    run(wgrad_kernel<T, ALOAD_ROW, 3, 2>, 64, "ns3 rs64 (now)", 512);
-    run(wgrad_kernel<T, ALOAD_ROW, 1, 2>, 64, "ns1 rs64", 512);
-    run(wgrad_kernel<T, ALOAD_ROW, 1, 1>, 32, "ns1 rs32 4blk/CU", 1024);
-    run(wgrad_kernel<T, ALOAD_ROW, 2, 1>, 32, "ns2 rs32", 1024);
-    run(wgrad_kernel<T, ALOAD_ROW, 1, 1>, 32, "ns1 rs32 768blk", 768);
+        for (int target : {256, 512}) {   // 256 x 256 tiles
+            auto kern = wgrad256_kernel;
+            const size_t smem = wgrad256_smem();
+            CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            WgradArgs a{}; a.Y = Y; a.ldy = sh.N; a.X = X; a.ldx = sh.K; a.dW = dW2; a.ldw = sh.K; a.db = db2; a.R = R; a.N = sh.N; a.K = sh.K;
+            const int tn = sh.N / 256, tk = sh.K / 256;
+            int splits = std::max(1, target / (tn * tk)); int rps = (R + splits - 1) / splits; rps = (rps + 31) / 32 * 32; splits = (R + rps - 1) / rps;
+            a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(512), smem, 0, a, R);
+            hipEventRecord(e0); for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(512), smem, 0, a, R); hipEventRecord(e1); hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1); CHECK(hipGetLastError());
+            printf("%-16s %-14s blocks %4d  %7.1f us  %6.1f TF/s  %5.2f TB/s", "256x256 dma", sh.name, tn * tk * splits, ms * 100, fl / (ms / 10 * 1e-3) / 1e12, by / (ms / 10 * 1e-3) / 1e12);
+            CHECK(hipMemset(dW2, 0, 1024 * 1024 * 4)); CHECK(hipMemset(db2, 0, 4096));
+            hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(512), smem, 0, a, R);
+            CHECK(hipDeviceSynchronize());
+            std::vector<float> h1((size_t)sh.N * sh.K), h2((size_t)sh.N * sh.K), b1(sh.N), b2(sh.N);
+            CHECK(hipMemcpy(h1.data(), dW, h1.size() * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h2.data(), dW2, h2.size() * 4, hipMemcpyDeviceToHost));
+            CHECK(hipMemcpy(b1.data(), db, sh.N * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b2.data(), db2, sh.N * 4, hipMemcpyDeviceToHost));
+            double num = 0, den = 0, bn = 0, bd = 0;
+            for (size_t i = 0; i < h1.size(); ++i) { num += (double)(h1[i] - h2[i]) * (h1[i] - h2[i]); den += (double)h1[i] * h1[i]; }
+            for (int i = 0; i < sh.N; ++i) { bn += (double)(b1[i] - b2[i]) * (b1[i] - b2[i]); bd += (double)b1[i] * b1[i]; }
+            printf("   rel_l2 dW %.2e db %.2e\n", std::sqrt(num / den), std::sqrt(bn / std::max(bd, 1e-30)));
+        }
+    }
     return 0;
 }
