@@ -162,11 +162,32 @@ __device__ __forceinline__ uint32_t drop_mask4(const Drop& d, uint32_t base) {
     return (uint32_t)((h0 & 0xFFFFu) >= d.thr) | ((uint32_t)((h0 >> 16) >= d.thr) << 1) |
            ((uint32_t)((h1 & 0xFFFFu) >= d.thr) << 2) | ((uint32_t)((h1 >> 16) >= d.thr) << 3);
 }
+// the 16-bit fields are compared in place (the compares land in scalar lane masks and feed v_cndmask directly):
+// building the 4-bit mask of drop_mask4 in a VGPR and testing its bits again costs ~2x the VALU of this form
 __device__ __forceinline__ void drop_apply4(const Drop& d, uint32_t base, f32x4& v) {
     if (d.thr == 0) return;
-    const uint32_t m = drop_mask4(d, base);
+    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    v[0] = (h0 & 0xFFFFu) >= d.thr ? v[0] * d.scale : 0.0f;
+    v[1] = (h0 >> 16) >= d.thr ? v[1] * d.scale : 0.0f;
+    v[2] = (h1 & 0xFFFFu) >= d.thr ? v[2] * d.scale : 0.0f;
+    v[3] = (h1 >> 16) >= d.thr ? v[3] * d.scale : 0.0f;
+}
+// ReLU + dropout of 4 consecutive elements in one select each; returns the 4 "kept and positive" bits (bit r)
+__device__ __forceinline__ uint32_t relu_drop_apply4(const Drop& d, uint32_t base, f32x4& v) {
+    bool on[4];
+    if (d.thr == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = ((m >> r) & 1u) ? v[r] * d.scale : 0.0f;
+        for (int r = 0; r < 4; ++r) { on[r] = v[r] > 0.0f; v[r] = on[r] ? v[r] : 0.0f; }
+    } else {
+        const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+        on[0] = v[0] > 0.0f && (h0 & 0xFFFFu) >= d.thr;
+        on[1] = v[1] > 0.0f && (h0 >> 16) >= d.thr;
+        on[2] = v[2] > 0.0f && (h1 & 0xFFFFu) >= d.thr;
+        on[3] = v[3] > 0.0f && (h1 >> 16) >= d.thr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = on[r] ? v[r] * d.scale : 0.0f;
+    }
+    return (uint32_t)on[0] | ((uint32_t)on[1] << 1) | ((uint32_t)on[2] << 2) | ((uint32_t)on[3] << 3);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -574,10 +574,11 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         a.d_emb = d_emb; a.d_raw = (float*)(ws + L.d_raw); a.dH = ws + L.c_dH;
         a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dwq = G(p_proj_w(c)); a.dbq = G(p_proj_b(c));
         auto kern = tail_bwd_kernel<T>;
-        GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
-        GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, st, a);
-        bucket(p_fn_w(c), p_proj_b(c));
+        GE2E_LAUNCH(h, kern, dim3((n / samples + TAIL_RB - 1) / TAIL_RB), dim3(256), 0, st, a);
+        sc.fork();                                        // projection weight gradient: off the critical chain
+        GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, wst, a);
     }
+    bool tail_bucket_pending = true;                      // reported after the first join with the side stream
     // diagnostics only: GE2E_DEBUG_BWD_STOP=k returns after k layers so ge2e_debug_tap sees that layer's scratch
     const char* dbg_stop = std::getenv("GE2E_DEBUG_BWD_STOP");
     const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
@@ -709,6 +710,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
         }
         if (cb) { hipEvent_t done = sc.mark(); sc.wait(done); }   // this layer's weight gradients are final before the bucket goes out
+        if (tail_bucket_pending) { bucket(p_fn_w(c), p_proj_b(c)); tail_bucket_pending = false; }
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
     {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place

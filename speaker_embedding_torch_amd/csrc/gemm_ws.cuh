@@ -203,11 +203,7 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
             const int col = n0 + nt * 16 + 4 * g;
             // staged 16 x 128 B slab, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); this lane: chunk 2nt + (g >> 1), half g & 1
             const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
-            if constexpr (EPI == EPI_BIAS_RELU_DROP) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-                drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
-            }
+            if constexpr (EPI == EPI_BIAS_RELU_DROP) (void)relu_drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
             if constexpr (EPI == EPI_MASK) {
                 const f32x4 m4 = load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
 #pragma unroll

@@ -183,34 +183,57 @@ __global__ void __launch_bounds__(256) tail_fwd_kernel(const TailArgs p) {
     if (c == 0 && p.nrm) p.nrm[m] = nn;
 }
 
+// TAIL_RB embeddings per block: the projection matrix is streamed from L2 once per block (32 loads in flight per
+// thread) and the LN_f gradient atomics shrink by the same factor.  grid = ceil(M / TAIL_RB), M = N / samples
+constexpr int TAIL_RB = 4;
 template <typename T>
 __global__ void __launch_bounds__(256) tail_bwd_kernel(const TailArgs p) {
     __shared__ float red[4];
-    __shared__ float dr[256];
-    const int m = blockIdx.x, c = threadIdx.x;
-    const float de = p.d_emb[(size_t)m * 256 + c], e = p.emb[(size_t)m * 256 + c];
-    const float dot = block256_sum(de * e, red);
-    const float draw = (de - e * dot) / p.nrm[m];
-    p.d_raw[(size_t)m * 256 + c] = draw;
-    dr[c] = draw;
+    __shared__ float dr[TAIL_RB][256];
+    const int c = threadIdx.x, M = p.N / p.samples;
+    const int mb = blockIdx.x * TAIL_RB;
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) {
+        const int m = mb + u;
+        float draw = 0.0f;
+        if (m < M) {                                   // block-uniform
+            const float de = p.d_emb[(size_t)m * 256 + c], e = p.emb[(size_t)m * 256 + c];
+            const float dot = block256_sum(de * e, red);
+            draw = (de - e * dot) / p.nrm[m];
+            p.d_raw[(size_t)m * 256 + c] = draw;
+        }
+        dr[u][c] = draw;
+    }
     __syncthreads();
-    float dzm = 0.0f;
-#pragma unroll 8
-    for (int j = 0; j < 256; ++j) dzm += dr[j] * p.wq[j * 256 + c];
-    const float dz = dzm / (float)p.samples;
+    float dzm[TAIL_RB];
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) dzm[u] = 0.0f;
+#pragma unroll 32
+    for (int j = 0; j < 256; ++j) {
+        const float w = p.wq[j * 256 + c];
+#pragma unroll
+        for (int u = 0; u < TAIL_RB; ++u) dzm[u] += dr[u][j] * w;
+    }
     const float g = p.gf[c];
-    float ag = 0.0f;
-    for (int s = 0; s < p.samples; ++s) {
-        const int row = m * p.samples + s;
-        const float xh = p.xhat[(size_t)row * 256 + c];
-        const float dxh = dz * g;
-        const float m1 = block256_sum(dxh, red) * (1.0f / 256.0f);
-        const float m2 = block256_sum(dxh * xh, red) * (1.0f / 256.0f);
-        ((T*)p.dH)[(size_t)row * p.T * 256 + c] = from_f32<T>(p.rstd[row] * (dxh - m1 - xh * m2));
-        ag += dz * xh;
+    float ag = 0.0f, ab = 0.0f;
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) {
+        const int m = mb + u;
+        if (m >= M) break;                             // block-uniform
+        const float dz = dzm[u] / (float)p.samples;
+        for (int s = 0; s < p.samples; ++s) {
+            const int row = m * p.samples + s;
+            const float xh = p.xhat[(size_t)row * 256 + c];
+            const float dxh = dz * g;
+            const float m1 = block256_sum(dxh, red) * (1.0f / 256.0f);
+            const float m2 = block256_sum(dxh * xh, red) * (1.0f / 256.0f);
+            ((T*)p.dH)[(size_t)row * p.T * 256 + c] = from_f32<T>(p.rstd[row] * (dxh - m1 - xh * m2));
+            ag += dz * xh;
+        }
+        ab += dz * (float)p.samples;
     }
     atomicAdd(p.dgf + c, ag);
-    atomicAdd(p.dbf + c, dz * (float)p.samples);
+    atomicAdd(p.dbf + c, ab);
 }
 
 // dWq[c][k] += sum_m d_raw[m][c] * zm[m][k]; dbq[c] += sum_m d_raw[m][c].  grid = (256 rows c, m-slices);
