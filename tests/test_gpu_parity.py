@@ -10,6 +10,7 @@ Tolerances (north_star: d-vectors within 1e-4 of the CPU reference on the fp32 p
               relative L2 <= 2e-2; gradients: cosine >= 0.98 per tensor and relative L2 <= 0.25
               (ReLU masks flip where a pre-activation is within bf16 rounding of zero).
 """
+import os
 from argparse import Namespace
 
 import numpy as np
@@ -273,3 +274,52 @@ def test_error_behaviour(mods):
     e = m(torch.zeros(2, 80, 32, device="cuda").requires_grad_(False))
     with pytest.raises(RuntimeError):
         e.sum().backward()      # eval forward keeps no activations / params need grad -> explicit error
+
+
+# ------------------------------------------------------------------------------------------ kernel-path agreement
+_PATH_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {tests!r})
+import test_gpu_parity as tp
+from oracle import ge2e_oracle as O
+from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+m, params, pe = tp.build(GE2E, "bf16", 0.1)
+m.train()
+x = torch.from_numpy(O.formula_mel(11, 12, 80, 77, logmel=True)).cuda()
+emb = m(x); loss = GE2E_Loss().cuda()(emb, 3); loss.backward()
+out = {{"emb": emb.detach().cpu().numpy(), "loss": np.float32(loss.item())}}
+for tap, w in (("qkv.1", 768), ("f.1", 1024), ("h2.1", 256), ("h1.0", 256)):
+    out["tap_" + tap] = m.workspace_view(tap, 12, 77, True).float().cpu().numpy()
+for k, p in m.named_parameters():
+    out["g_" + k] = p.grad.cpu().numpy()
+np.savez({out!r}, **out)
+"""
+
+
+def test_bf16_streaming_and_tiled_kernels_agree(mods, tmp_path):
+    """The bf16 mode runs the K=256 products on gemm_ws_kernel and FFN2+LN on gemm_kl_kernel; GE2E_NO_WS_GEMM /
+    GE2E_NO_KL_GEMM put the same step on the tiled gemm_nt_kernel (the kernels the fp32 parity mode uses).  Same
+    dropout stream, same inputs, ragged rows (12 x 77 = 924: not a multiple of the 16- and 128-row tiles): the
+    projections are bit-identical between the two, the LayerNorm statistics are summed in a different order."""
+    import subprocess, sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, extra in (("stream", {}), ("tiled", {"GE2E_NO_WS_GEMM": "1", "GE2E_NO_KL_GEMM": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        env = dict(os.environ, **extra)
+        code = _PATH_SCRIPT.format(repo=repo, tests=os.path.join(repo, "tests"), out=out)
+        r = subprocess.run([_sys.executable, "-c", code], env=env, cwd=repo, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = dict(np.load(out))
+    a, b = res["stream"], res["tiled"]
+    # first product of the path: in_proj of layer 1 sees inputs that already went through one LayerNorm pair
+    assert np.array_equal(res["stream"]["tap_h1.0"].shape, res["tiled"]["tap_h1.0"].shape)
+    assert rel_l2(a["tap_h1.0"], b["tap_h1.0"]) < 2e-3        # first LayerNorm output: bf16 rounding flips only
+    for k in ("tap_qkv.1", "tap_f.1", "tap_h2.1"):
+        assert rel_l2(a[k], b[k]) < 6e-3, k
+    assert np.abs(a["emb"] - b["emb"]).max() < 3e-3 and abs(float(a["loss"]) - float(b["loss"])) < 5e-3
+    for k in a:
+        if k.startswith("g_") and a[k].size > 1:
+            g, r = a[k].ravel().astype(np.float64), b[k].ravel().astype(np.float64)
+            cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            assert cos > 0.995, (k, cos)
