@@ -85,11 +85,17 @@ int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_u
                           const float* const* params, const float* d_emb, float* grads_flat,
                           void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step);
 
-/* Same, reporting gradient buckets as soon as their last kernel has been ENQUEUED on `stream` (replaces the
- * post-backward queue_callback of reference distributed.py:114-118): cb(user, element_offset, element_count)
- * is called on the calling host thread, in this order: [final norm + projection], [layer L-1], ..., [layer 0],
- * [prenet + alpha].  The caller records an event and starts that bucket's all-reduce on its comm stream. */
+/* Same, reporting gradient buckets as soon as their last kernel has been ENQUEUED (replaces the post-backward
+ * queue_callback of reference distributed.py:114-118): cb(user, element_offset, element_count) is called on the
+ * calling host thread, in this order: [final norm + projection], [layer L-1], ..., [layer 0], [prenet + alpha].
+ * At the time of the call everything that writes the bucket is enqueued on ge2e_bucket_stream(h, stream) -- the
+ * library's weight-gradient stream, which the caller's `stream` does NOT wait for until the call returns -- so the
+ * caller orders that bucket's all-reduce behind THAT stream (record an event there / make it current) and the
+ * backward chain on `stream` is not held up by the hand-off. */
 typedef void (*ge2e_bucket_cb)(void* user, int64_t element_offset, int64_t element_count);
+/* The stream behind which a bucket reported by ge2e_encoder_backward_cb(…, stream, …) is final: the internal
+ * weight-gradient stream, or `stream` itself when the overlap is off (GE2E_NO_OVERLAP).  Valid inside the callback. */
+void* ge2e_bucket_stream(ge2e_handle h, void* stream);
 int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
                              const float* const* params, const float* d_emb, float* grads_flat,
                              void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,

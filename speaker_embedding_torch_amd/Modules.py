@@ -162,7 +162,7 @@ class _EncoderFn(torch.autograd.Function):
         grads = torch.empty(hnd.param_total, device=features.device, dtype=torch.float32)
         stream = torch.cuda.current_stream(features.device).cuda_stream
         sync = module._grad_sync
-        cb = sync.bucket_callback(grads) if sync is not None else None
+        cb = sync.bucket_callback(grads, hnd, stream) if sync is not None else None
         hnd.encoder_backward(stream, features, n, t, samples, ptrs, d_emb, grads, ctx.ws, seed, step, cb)
         if sync is not None:
             sync.finish(grads)

@@ -44,6 +44,7 @@ _SIG = {
     "ge2e_encoder_backward_cb": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                            C.c_uint64, C.c_uint64, BUCKET_CB, C.c_void_p]),
+    "ge2e_bucket_stream": (C.c_void_p, [C.c_void_p, C.c_void_p]),
     "ge2e_loss_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ge2e_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -139,6 +140,10 @@ class Handle:
                                                    grads.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
                                                    seed, step, cb, None)
         self.check(rc, "ge2e_encoder_backward")
+
+    def bucket_stream(self, stream):
+        """Raw hipStream_t behind which the buckets of encoder_backward(…, cb) are final (valid inside the callback)."""
+        return self.lib.ge2e_bucket_stream(self._h, stream) or 0
 
     def loss_workspace_bytes(self, speakers, utts):
         return self.lib.ge2e_loss_workspace_bytes(speakers, utts, self.cfg.emb)

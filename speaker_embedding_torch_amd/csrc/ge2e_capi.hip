@@ -709,7 +709,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             g.C = ws + L.dHa; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
             CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
         }
-        if (cb) { hipEvent_t done = sc.mark(); sc.wait(done); }   // this layer's weight gradients are final before the bucket goes out
+        if (cb) sc.fork();     // the bucket is final behind the side stream (ge2e_bucket_stream): it now also follows this layer's main-stream kernels
         if (tail_bucket_pending) { bucket(p_fn_w(c), p_proj_b(c)); tail_bucket_pending = false; }
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
@@ -725,9 +725,9 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         w.Y = ws + L.dHa; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
         CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
+        if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
         hipEvent_t done = sc.mark();
         sc.wait(done);                                   // join: the caller's stream owns every gradient again
-        bucket(P_PRENET_W, P_ALPHA);
     }
     if (sc.err) return fail(h, GE2E_EINVAL, "side-stream event fencing failed");
     return 0;
@@ -915,6 +915,11 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
             else GE2E_LAUNCH(h, opt_adamw_kernel, dim3(chunks), dim3(256), 0, st, a);
         }
     return 0;
+}
+
+void* ge2e_bucket_stream(ge2e_handle h, void* stream) {
+    if (!h || !h->overlap || !h->side) return stream;
+    return (void*)h->side;
 }
 
 int ge2e_profile_enable(ge2e_handle h, int class_mask) {

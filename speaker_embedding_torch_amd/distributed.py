@@ -9,6 +9,8 @@ issued immediately with async_op=True, so RCCL runs it on its own stream behind 
 produced it and overlaps the rest of backward.  One process per GPU; semantics per rank are the
 reference's (each rank draws its own speakers and computes a local GE2E loss, Train.py:90-99).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,18 +39,30 @@ class GradSync:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group)
+        # RCCL averages in the collective (ncclAvg); gloo has no AVG: sum, then one scaling pass
+        self._avg = dist.get_backend(group) == "nccl" and not os.environ.get("GE2E_ALLREDUCE_SUM")
         self._works = []
         self._error = None
         self.buckets_seen = []          # (offset, count) of the last backward, for tests / logging
 
-    def bucket_callback(self, grads_flat):
+    def bucket_callback(self, grads_flat, handle=None, stream=0):
+        """`handle`/`stream`: the library handle and the raw stream the backward runs on.  A bucket is final behind
+        handle.bucket_stream(stream) (the weight-gradient stream), so its all-reduce is issued with THAT stream
+        current: RCCL's stream then waits for exactly the bucket's producers and the backward chain is not held."""
         self._works, self._error, self.buckets_seen = [], None, []
 
         def on_bucket(_user, offset, count):
             try:        # exceptions must not unwind through the C frame
                 self.buckets_seen.append((int(offset), int(count)))
                 view = grads_flat[offset:offset + count]
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                ptr = handle.bucket_stream(stream) if (handle is not None and grads_flat.is_cuda) else 0
+                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+                if ptr and ptr != stream:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(ptr, device=grads_flat.device)):
+                        w = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+                else:
+                    w = dist.all_reduce(view, op=op, group=self.group, async_op=True)
+                self._works.append(w)
             except BaseException as ex:  # noqa: BLE001
                 self._error = ex
         return _lib.BUCKET_CB(on_bucket)
@@ -61,7 +75,8 @@ class GradSync:
             if w is not None:
                 w.wait()
         self._works = []
-        grads_flat.mul_(1.0 / self.world)
+        if not self._avg:
+            grads_flat.mul_(1.0 / self.world)
 
 
 def apply_gradient_allreduce(module, group=None):
