@@ -193,3 +193,33 @@ def test_fused_clip_adamw_matches_torch():
         assert torch.allclose(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=1e-5, atol=1e-8)
     ob2 = torch.optim.AdamW(pb, **kw)
     ob2.load_state_dict(sa)                                                       # torch loads the fused optimizer's state
+
+
+@pytest.mark.parametrize("bf16", [True, False])
+def test_training_learns_synthetic_speakers(tmp_path, bf16):
+    """End to end through Trainer.Train_Step (forward, GE2E loss, backward, clip, AdamW; dropout on): on mel batches whose
+    only structure is a per-speaker spectral envelope the loss must fall well below its initial value within 40 steps and
+    held-out utterances of a speaker must end up closer to their own centroid than to any other."""
+    from speaker_embedding_torch_amd.Train import Trainer
+    S, P, T = 8, 6, 64
+    hp_path = write_hp(tmp_path, bf16=bf16, **{"Train.Batch.Train.Speaker": S, "Train.Batch.Train.Pattern_per_Speaker": P,
+                                               "Train.Learning_Rate.Initial": 5e-4})
+    tr = Trainer(hp_path, datasets={})
+    g = torch.Generator().manual_seed(0)
+    envelopes = torch.randn(S, 80, 1, generator=g) * 1.5                        # what identifies a speaker
+
+    def batch(seed):
+        gg = torch.Generator().manual_seed(seed)
+        x = envelopes[:, None].expand(S, P, 80, 1) + torch.randn(S, P, 80, T, generator=gg)
+        return x.reshape(S * P, 80, T).contiguous()
+
+    losses = [tr.Train_Step(batch(100 + i)).item() for i in range(40)]
+    assert all(np.isfinite(losses))
+    first, last = np.mean(losses[:3]), np.mean(losses[-5:])
+    assert last < 0.5 * first, (first, last)
+    tr.model.eval()
+    with torch.no_grad():
+        e = tr.model(batch(999).cuda()).float().cpu().reshape(S, P, 256)
+    cent = torch.nn.functional.normalize(e.mean(1), dim=1)
+    sim = torch.einsum("spd,cd->spc", e, cent)                                   # [S, P, S]
+    assert (sim.argmax(-1) == torch.arange(S)[:, None]).float().mean() > 0.9
