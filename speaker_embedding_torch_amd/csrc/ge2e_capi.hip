@@ -259,6 +259,22 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     return 0;
 }
 
+// LayerNorm backward + the K = 256 GEMM that consumes it, one launch (gemm_ws_lnbwd_kernel).  a.A = dy, a.gamma / beta /
+// rstd / drop / drow_mul describe the LayerNorm and the dropout in front of the sub-layer, f the rest.
+inline bool lnfuse_on() { static const bool off = getenv("GE2E_NO_LNFUSE") != nullptr; return !off; }
+template <int EPI>
+int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const LnFuseArgs& f) {
+    const int cg = a.N / 256, ntiles = (a.M + 15) / 16;
+    int parts = (512 / cg) / 8 * 8;
+    if (parts > (ntiles + 7) / 8 * 8) parts = (ntiles + 7) / 8 * 8;
+    if (parts < 8) parts = 8;
+    const double abytes = 2.0 * ((double)a.M * 256 * (f.dmask ? 4.0 : 3.0) + (double)a.N * a.K + (double)a.M * a.N * (EPI == EPI_MASK ? 2.0 : 1.0));
+    ProfScope ps(h, st, GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
+    auto kern = gemm_ws_lnbwd_kernel<EPI>;
+    GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_lnbwd_smem<EPI>()), st, a, f, parts, ntiles);
+    return 0;
+}
+
 template <typename T, int EPI, int ALOAD = ALOAD_ROW>
 int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI>() && ALOAD == ALOAD_ROW) {
@@ -613,7 +629,8 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         }
         unsigned char* gm = d_ff.thr ? b_dM : b_dP;
         sc.wait(g_dF);
-        {   // dF = (dG W2) masked by ReLU/dropout of the hidden
+        {   // dF = (dG W2) masked by ReLU/dropout of the hidden.  (Fusing norm2's backward into this GEMM as it is fused into
+            // dO below was measured and lost: its four column-group blocks each redo the LayerNorm prologue, 327 vs 260 us.)
             GemmArgs a{};
             a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = b_dF; a.ldc = c.ffn;
             a.M = Rl; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
@@ -641,6 +658,19 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             CK((gemm128<T, EPI_ADD>(h, st, a)));
         }
         sc.wait(g_set2);
+        gm = d_sa.thr ? b_dM2 : b_dP2;
+        GemmArgs ado{};        // dO = dA Wo
+        ado.A = gm; ado.lda = d; ado.W = ws + L.w_outT[l]; ado.ldw = d; ado.C = b_dO; ado.ldc = d;
+        ado.M = Rl; ado.N = d; ado.K = d;
+        if (ws_epilogue<T, EPI_MASK>() && ws_shape(ado) && lnfuse_on()) {
+            // norm1 backward rides in the prologue of the dO GEMM
+            LnFuseArgs f{};
+            f.y = ws + L.h1[l]; f.ldy = d; f.dpre = b_dP2; f.dmask = d_sa.thr ? b_dM2 : nullptr;
+            f.dgamma = G(lp(l, L_N1_W)); f.dbeta = G(lp(l, L_N1_B));
+            ado.A = b_dHb; ado.gamma = P[lp(l, L_N1_W)]; ado.beta = P[lp(l, L_N1_B)];
+            ado.rstd = (float*)(ws + L.rstd1[l]); ado.drop = d_sa; ado.drow_mul = rmul;
+            CK((launch_gemm_ws_lnbwd<EPI_NONE>(h, st, ado, f)));
+        } else {
         {   // norm1 backward
             LnBwdArgs a{};
             a.dy = b_dHb; a.y = ws + L.h1[l]; a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)];
@@ -650,12 +680,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
             ProfScope ps(h, st, GE2E_K_LN_BWD, 12.0 * Rl * d, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        gm = d_sa.thr ? b_dM2 : b_dP2;
-        {   // dO = dA Wo
-            GemmArgs a{};
-            a.A = gm; a.lda = d; a.W = ws + L.w_outT[l]; a.ldw = d; a.C = b_dO; a.ldc = d;
-            a.M = Rl; a.N = d; a.K = d;
-            CK((gemm128<T, EPI_NONE>(h, st, a)));
+        CK((gemm128<T, EPI_NONE>(h, st, ado)));
         }
         sc.fork();
         {

@@ -221,4 +221,235 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward fused into the weight-stationary GEMM that consumes its result (bf16 mode, K = 256 = the model
+// width, so an A tile is 16 WHOLE rows):
+//     dx    = LN_backward(dy, y, rstd, gamma, beta)         -> dpre  (residual path)
+//     dm    = dropout(dx)                                    -> dmask (input gradient of the sub-layer)
+//     C     = epilogue(dm . W^T)                             (EPI_MASK: dF = (dG W2) o relu'/dropout;  EPI_NONE: dO = dA Wo)
+// replaces ln_bwd_kernel + gemm_ws/gemm_nt: the dm tile never comes back from HBM and one launch disappears from the
+// backward chain.  dy and y tiles arrive by LDS-DMA (every wave fetches the 4 rows it will process: its own counted
+// wait is enough before the prologue); the prologue is the wave-per-row LayerNorm-backward of misc.cuh, writes dpre /
+// dmask rows straight to HBM (512 contiguous bytes per row; column group 0 only) and overwrites the dy tile in LDS
+// with dm, which the MFMA phase then reads as its A operand.  dgamma / dbeta accumulate in registers over the block's
+// whole life (persistent blocks: one atomic flush per block).  Rings of 4 slots (EPI_NONE, 76 KB) or 3 slots (EPI_MASK with
+// its mask ring, 75 KB): two blocks per CU.  In the step only the EPI_NONE form (norm1 backward + dO) is used: with EPI_MASK
+// the four column-group blocks of a row partition each redo the prologue and the fused launch lost (327 vs 260 us).
+// ---------------------------------------------------------------------------------------------
+struct LnFuseArgs {
+    const void* y; int ldy;      // saved LayerNorm OUTPUT [M, 256] of T (xhat is rebuilt from it)
+    void* dpre;                  // [M, 256] of T
+    void* dmask;                 // [M, 256] of T, or null when the dropout is inactive (then A = dpre)
+    float* dgamma; float* dbeta; // [256] fp32, atomically accumulated
+};
+
+template <int EPI> constexpr int wsf_nstg() { return EPI == EPI_MASK ? 3 : 4; }   // the mask ring costs a slot (two blocks per CU)
+template <int EPI>
+constexpr size_t gemm_ws_lnbwd_smem() {
+    constexpr int NSTG = wsf_nstg<EPI>();
+    return (size_t)NSTG * 8192 * 2 + (EPI == EPI_MASK ? 4 * NSTG * 2048 : 4 * 2048) + (size_t)NSTG * 4 * 256;
+}
+
+template <int N, int D> struct WsfWait {
+    static __device__ __forceinline__ void at(int t, int st) {   // st = stores per tile of this block: 2, 6 or 10
+        const int k = t < D ? t : D;                              // tiles whose stores lie behind tile t's DMAs
+        // younger operations than tile t's DMAs: (D-1) tiles of N DMAs + k tiles of st stores
+        static_assert(D == 2 || D == 3, "ring depth");
+        if (st == 2) {
+            if (k == 0) wait_vmcnt<(D - 1) * N>(); else if (k == 1) wait_vmcnt<(D - 1) * N + 2>();
+            else if (k == 2) wait_vmcnt<(D - 1) * N + 4>(); else wait_vmcnt<(D - 1) * N + 6>();
+        } else if (st == 6) {
+            if (k == 0) wait_vmcnt<(D - 1) * N>(); else if (k == 1) wait_vmcnt<(D - 1) * N + 6>();
+            else if (k == 2) wait_vmcnt<(D - 1) * N + 12>(); else wait_vmcnt<(D - 1) * N + 18>();
+        } else {
+            if (k == 0) wait_vmcnt<(D - 1) * N>(); else if (k == 1) wait_vmcnt<(D - 1) * N + 10>();
+            else if (k == 2) wait_vmcnt<(D - 1) * N + 20>(); else wait_vmcnt<(D - 1) * N + 30>();
+        }
+    }
+};
+
+template <int EPI>
+__global__ void __launch_bounds__(256, 2) gemm_ws_lnbwd_kernel(const GemmArgs p, const LnFuseArgs q, const int parts, const int ntiles) {
+    using T = bf16_t;
+    static_assert(EPI == EPI_MASK || EPI == EPI_NONE, "consumers of a LayerNorm backward");
+    constexpr int KGN = 8, ROWB = 512, ATILE = 16 * ROWB;
+    constexpr bool HAS_R = (EPI == EPI_MASK);
+    constexpr int NSTG = wsf_nstg<EPI>(), D = NSTG - 1;
+    constexpr int PER = 2 + 2 + (HAS_R ? 2 : 0) + 1;          // dy, y, mask slab, rstd
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const As = smem;                               // [NSTG][16][512]  dy, overwritten with dm
+    unsigned char* const Ys = smem + NSTG * ATILE;                // [NSTG][16][512]  y
+    unsigned char* const Rs = Ys + NSTG * ATILE;                  // [4 waves][NSTG][2048] mask slabs (EPI_NONE: [4][2048] output stage)
+    float* const Qs = (float*)(Rs + (HAS_R ? 4 * NSTG * 2048 : 4 * 2048));   // [NSTG][4 waves][64] rstd of the wave's rows (lane & 3)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int CG = p.N / 256;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int cg = slot % CG, part = (slot / CG) * 8 + xcd;
+    const int n0 = cg * 256 + wave * 64;
+    const int my = part < ntiles ? (ntiles - part + parts - 1) / parts : 0;
+    if (my == 0) return;
+    const bool writer = cg == 0;                                  // one column group writes dpre / dmask / dgamma / dbeta
+    const int st_per = writer ? (q.dmask ? 10 : 6) : 2;
+
+    u32x4 wf[4][KGN];
+    const int c0 = lane * 4;                                      // LayerNorm-backward: 4 columns per lane
+    f32x4 ga, be, ig;
+    {
+        const unsigned char* W = (const unsigned char*)p.W;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kg = 0; kg < KGN; ++kg)
+                wf[nt][kg] = *(const u32x4*)(W + ((size_t)(n0 + nt * 16 + i) * p.ldw + kg * 32 + g * 8) * 2);
+        ga = *(const f32x4*)(p.gamma + c0); be = *(const f32x4*)(p.beta + c0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ig[r] = ga[r] != 0.0f ? 1.0f / ga[r] : 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int kg = 0; kg < KGN; ++kg) asm volatile("" : "+v"(wf[nt][kg]));
+        asm volatile("" : "+v"(ga), "+v"(be), "+v"(ig));
+    }
+
+    const unsigned char* const Ag = (const unsigned char*)p.A;
+    const unsigned char* const Yg = (const unsigned char*)q.y;
+    const unsigned char* const Rg = (const unsigned char*)p.R;
+    const int last_row = p.M - 1;
+    auto issue = [&](int j) {
+        const int jj = j < my ? j : my - 1;
+        const int r0 = (part + jj * parts) * 16, s = j % NSTG;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                             // this wave's 4 rows of dy and of y: 2 rows per instruction
+            const int r = 4 * wave + 2 * u + (lane >> 5), pos = lane & 31;
+            const int c = pos ^ (r & 15);
+            int gr = r0 + r; gr = gr < last_row ? gr : last_row;
+            glds16(Ag + (size_t)gr * p.lda * 2 + c * 16, As + s * ATILE + (4 * wave + 2 * u) * ROWB);
+            glds16(Yg + (size_t)gr * q.ldy * 2 + c * 16, Ys + s * ATILE + (4 * wave + 2 * u) * ROWB);
+        }
+        if constexpr (HAS_R) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = u * 8 + (lane >> 3), pos = lane & 7;
+                const int c = pos ^ ((r >> 1) & 7);
+                int gr = r0 + r; gr = gr < last_row ? gr : last_row;
+                glds16(Rg + ((size_t)gr * p.ldr + n0) * 2 + c * 16, Rs + (wave * NSTG + s) * 2048 + u * 1024);
+            }
+        }
+        {
+            int gr = r0 + 4 * wave + (lane & 3); gr = gr < last_row ? gr : last_row;
+            __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)(p.rstd + gr), (lds_void_t*)(Qs + (s * 4 + wave) * 64), 4, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) issue(j);
+
+    T* const Cg = (T*)p.C;
+    const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
+    f32x4 ag = f32x4{0, 0, 0, 0}, ab = f32x4{0, 0, 0, 0};
+    // position of this lane's 4 columns (8 bytes) inside a swizzled 512-byte row: chunk lane >> 1, half lane & 1
+    const int lch = lane >> 1, lhf = (lane & 1) * 8;
+
+#pragma unroll 1
+    for (int t = 0; t < my; ++t) {
+        WsfWait<PER, D>::at(t, st_per);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // tile t is in (each wave: its own rows; the barrier orders the slot reuse)
+        __builtin_amdgcn_sched_barrier(0);
+        issue(t + D);
+        const int s = t % NSTG;
+        const int r0 = (part + t * parts) * 16;
+        unsigned char* const a = As + s * ATILE;
+        const unsigned char* const yt = Ys + s * ATILE;
+        // ---- prologue: LayerNorm backward of this wave's 4 rows, two at a time (two independent rows interleave their
+        // reductions; four at once cost 32 more VGPRs and the second resident block)
+#pragma unroll 1
+        for (int h2 = 0; h2 < 2; ++h2) {
+            f32x4 dx[2], xh[2];
+            float s1[2], s2[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 4 * wave + 2 * h2 + u;
+                const int off = r * ROWB + ((lch ^ (r & 15)) << 4) + lhf;
+                const f32x4 dy = load4((const T*)(a + off));
+                const f32x4 y = load4((const T*)(yt + off));
+                float t1 = 0.0f, t2 = 0.0f;
+                const bool live = r0 + r < p.M;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[u][e] = (y[e] - be[e]) * ig[e];
+                    dx[u][e] = dy[e] * ga[e];
+                    t1 += dx[u][e];
+                    t2 += dx[u][e] * xh[u][e];
+                    if (live) { ag[e] += dy[e] * xh[u][e]; ab[e] += dy[e]; }
+                }
+                s1[u] = t1; s2[u] = t2;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { s1[u] = wave_sum(s1[u]) * (1.0f / 256.0f); s2[u] = wave_sum(s2[u]) * (1.0f / 256.0f); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 4 * wave + 2 * h2 + u, row = r0 + r;
+                const int off = r * ROWB + ((lch ^ (r & 15)) << 4) + lhf;
+                const float rs = Qs[(s * 4 + wave) * 64 + 2 * h2 + u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dx[u][e] = rs * (dx[u][e] - s1[u] - xh[u][e] * s2[u]);
+                if (writer && row < p.M) store4((T*)q.dpre + (size_t)row * 256 + c0, dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+                if (q.dmask) {
+                    drop_apply4(p.drop, (uint32_t)row * drm * 256u + (uint32_t)c0, dx[u]);
+                    if (writer && row < p.M) store4((T*)q.dmask + (size_t)row * 256 + c0, dx[u][0], dx[u][1], dx[u][2], dx[u][3]);
+                }
+                store4((T*)(a + off), dx[u][0], dx[u][1], dx[u][2], dx[u][3]);      // the GEMM's A operand
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA phase
+        f32x4 acc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < KGN; ++kg) {
+            const u32x4 af = lds16(a + swz_off<ROWB>(i, kg * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt] = mma16<T>(wf[nt][kg], af, acc[nt]);
+        }
+        // ---- wave-private epilogue through the wave's mask slab (EPI_MASK: read, then reused as the output stage)
+        unsigned char* const Ow = HAS_R ? Rs + (wave * NSTG + s) * 2048 : Rs + wave * 2048;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 v = acc[nt];
+            const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
+            if constexpr (EPI == EPI_MASK) {
+                const f32x4 m4 = load4((const T*)(Ow + so));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
+            }
+            store4((T*)(Ow + so), v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = u * 8 + (lane >> 3), c = lane & 7;
+            const u32x4 o = lds16(Ow + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            if (r0 + r < p.M) __builtin_nontemporal_store(o, (u32x4*)((unsigned char*)Cg + ((size_t)(r0 + r) * p.ldc + n0) * 2 + c * 16));
+        }
+    }
+    // ---- dgamma / dbeta: combine the four waves through LDS, one atomic per column and block
+    wait_vmcnt<0>();
+    __syncthreads();
+    if (writer) {
+        float* const red = (float*)smem;                          // [2][4][256]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { red[(0 * 4 + wave) * 256 + c0 + e] = ag[e]; red[(1 * 4 + wave) * 256 + c0 + e] = ab[e]; }
+        __syncthreads();
+        const int c = tid;
+        atomicAdd(q.dgamma + c, red[c] + red[256 + c] + red[512 + c] + red[768 + c]);
+        atomicAdd(q.dbeta + c, red[1024 + c] + red[1280 + c] + red[1536 + c] + red[1792 + c]);
+    }
+}
+
 }  // namespace ge2e
