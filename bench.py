@@ -102,6 +102,11 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer: BASELINE.json configs[3] style embed-only run (eval forward, --samples slices per utterance)")
     ap.add_argument("--samples", type=int, default=5)
+    ap.add_argument("--input", default="resident", choices=["resident", "host32", "host16"],
+                    help="resident: batches already in HBM (the metric's definition). host32 / host16: every step first brings "
+                         "its batch from pinned host memory as float32 / float16 -- the PCIe-inclusive rate quoted in DESIGN.md, "
+                         "never the headline value")
+    ap.add_argument("--prefetch", action="store_true", help="with --input host*: copy batch i+1 on a side stream under step i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-every", type=int, default=4, help="profile the roofline kernel class on every N-th timed step")
@@ -161,9 +166,34 @@ def main():
               "unit_norm_err": float((e.norm(dim=1) - 1).abs().max())})
         return
 
+    host = None
+    if args.input != "resident":
+        hdt = torch.float16 if args.input == "host16" else torch.float32
+        host = [b.to(hdt).cpu().pin_memory() for b in batches]
+        copy_stream = torch.cuda.Stream(dev) if args.prefetch else None
+        staged = {}
+
+        def fetch(i):
+            """H2D of step i's batch: on the compute stream (no prefetch) or on the copy stream, fenced by an event."""
+            if copy_stream is None:
+                return host[i & 1].to(dev, non_blocking=True)
+            if i not in staged:
+                with torch.cuda.stream(copy_stream):
+                    t = host[i & 1].to(dev, non_blocking=True)
+                    e = torch.cuda.Event(); e.record(copy_stream)
+                staged[i] = (t, e)
+            t, e = staged.pop(i)
+            with torch.cuda.stream(copy_stream):      # start the next one before this step's kernels are enqueued
+                tn = host[(i + 1) & 1].to(dev, non_blocking=True)
+                en = torch.cuda.Event(); en.record(copy_stream)
+            staged[i + 1] = (tn, en)
+            torch.cuda.current_stream(dev).wait_event(e)
+            t.record_stream(torch.cuda.current_stream(dev))
+            return t
+
     def train_step(i):
         """Trainer.Train_Step (Train.py:140-168) without the logging-only loss.item() host sync."""
-        emb = model(batches[i & 1])
+        emb = model(batches[i & 1] if host is None else fetch(i))
         loss = criterion(emb, P)
         optimizer.zero_grad()
         loss.backward()
@@ -233,6 +263,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "input": args.input + ("+prefetch" if (args.prefetch and args.input != "resident") else ""),
             "config": {"workload": f"{S} spk x {P} utt x {T} fr x {mel} mel per GPU, full Train_Step "
                                    f"(fwd+GE2E loss+bwd+clip+AdamW), dropout 0.1, random-init weights",
                        "per_gpu_batch": S * P, "global_batch": S * P * world,

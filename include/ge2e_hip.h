@@ -78,7 +78,15 @@ int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_ut
                          const float* const* params, const float* pe, float* out_emb,
                          void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step);
 
+/* Same forward from an IEEE fp16 mel batch [n_utts, mel_dim, frames] (the reference stores patterns as fp16,
+ * Pattern_Generator.py:191-198, and widens them on the host, Datasets.py:84): the batch crosses PCIe at half the size
+ * and is widened by the packing pass.  Results are identical to ge2e_encoder_forward on the widened values. */
+int ge2e_encoder_forward_mel16(ge2e_handle h, void* stream, const void* mel_f16, int n_utts, int frames, int samples,
+                               const float* const* params, const float* pe, float* out_emb,
+                               void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step);
+
 /* Must follow a train-mode forward on the SAME workspace, inputs, seed and step.
+ * mel:        the forward's input pointer (either dtype; not read again: the packed rows live in the workspace)
  * d_emb:      device fp32 [n_utts / samples, emb]
  * grads_flat: device fp32 [ge2e_param_total()], OVERWRITTEN with dL/dparam at ge2e_param_offset(i) */
 int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,

@@ -119,8 +119,8 @@ class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, features, samples, *params):
         _require_gpu(features, "features")
-        if features.dim() != 3 or features.dtype != torch.float32:
-            raise RuntimeError("features must be float32 [Batch * Sample, Mel_dim, Time]")
+        if features.dim() != 3 or features.dtype not in (torch.float32, torch.float16):
+            raise RuntimeError("features must be float32 (or float16: SURVEY row f2) [Batch * Sample, Mel_dim, Time]")
         features = features.contiguous()
         n, mel, t = features.shape
         hnd = module._handle()

@@ -38,6 +38,9 @@ _SIG = {
     "ge2e_encoder_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.c_int, C.c_uint64, C.c_uint64]),
+    "ge2e_encoder_forward_mel16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                             C.c_int, C.c_uint64, C.c_uint64]),
     "ge2e_encoder_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                         C.c_uint64, C.c_uint64]),
@@ -127,9 +130,11 @@ class Handle:
         return arr
 
     def encoder_forward(self, stream, mel, n, t, samples, ptrs, pe, out, ws, train, seed, step):
-        self.check(self.lib.ge2e_encoder_forward(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, pe.data_ptr(),
-                                                 out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
-                                                 1 if train else 0, seed, step), "ge2e_encoder_forward")
+        """mel: device float32 or float16 [n, mel_dim, t] (the fp16 form is widened by the packing kernel)."""
+        fn = self.lib.ge2e_encoder_forward_mel16 if str(mel.dtype) == "torch.float16" else self.lib.ge2e_encoder_forward
+        self.check(fn(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, pe.data_ptr(),
+                      out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
+                      1 if train else 0, seed, step), "ge2e_encoder_forward")
 
     def encoder_backward(self, stream, mel, n, t, samples, ptrs, d_emb, grads, ws, seed, step, cb=None):
         if cb is None:

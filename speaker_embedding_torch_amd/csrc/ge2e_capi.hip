@@ -436,7 +436,7 @@ struct SideCtx {
 };
 
 template <typename T>
-int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
+int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, int n, int t, int samples,
                  const float* const* P, const float* pe, float* out_emb, unsigned char* ws, const Layout& L,
                  bool train, uint64_t seed, uint64_t step) {
     const ge2e_config& c = h->cfg;
@@ -473,9 +473,12 @@ int forward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, 
                     P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
     }
     // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
-    {
-        auto kern = mel_pack_kernel<T>;
-        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
+    if (mel_f16) {
+        auto kern = mel_pack_kernel<T, _Float16>;
+        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, (const _Float16*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
+    } else {
+        auto kern = mel_pack_kernel<T, float>;
+        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, (const float*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
     }
     // ---- prenet + ReLU + positional encoding (+ dropout)
     {
@@ -830,9 +833,9 @@ size_t ge2e_workspace_bytes(ge2e_handle h, int n_utts, int frames, int train) {
     return build_layout(h->cfg, n_utts, frames, train).total;
 }
 
-int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
-                         const float* const* params, const float* pe, float* out_emb,
-                         void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step) {
+static int encoder_forward_any(ge2e_handle h, void* stream, const void* mel, bool mel_f16, int n_utts, int frames, int samples,
+                               const float* const* params, const float* pe, float* out_emb,
+                               void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step) {
     if (!h) return GE2E_EINVAL;
     if (!mel || !params || !pe || !out_emb) return fail(h, GE2E_EINVAL, "null pointer argument");
     for (size_t i = 0; i < h->params.size(); ++i)
@@ -842,8 +845,20 @@ int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_ut
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     if (h->cfg.precision == GE2E_PREC_BF16)
-        return forward_impl<bf16_t>(h, st, mel, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
-    return forward_impl<float>(h, st, mel, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+        return forward_impl<bf16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+    return forward_impl<float>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+}
+
+int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
+                         const float* const* params, const float* pe, float* out_emb,
+                         void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step) {
+    return encoder_forward_any(h, stream, mel, false, n_utts, frames, samples, params, pe, out_emb, workspace, workspace_bytes, train, seed, step);
+}
+
+int ge2e_encoder_forward_mel16(ge2e_handle h, void* stream, const void* mel_f16, int n_utts, int frames, int samples,
+                               const float* const* params, const float* pe, float* out_emb,
+                               void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step) {
+    return encoder_forward_any(h, stream, mel_f16, true, n_utts, frames, samples, params, pe, out_emb, workspace, workspace_bytes, train, seed, step);
 }
 
 int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,

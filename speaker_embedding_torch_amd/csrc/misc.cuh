@@ -62,14 +62,15 @@ __global__ void __launch_bounds__(256) transpose_f32_kernel(const float* src, fl
 // mel batch fp32 [N][mel][T] (channels-first, contiguous along T) -> row-major T-typed [N*T][KP], zero beyond mel.
 // One coalesced streaming pass (reads along t, writes along k through a 32x32 LDS tile); afterwards the prenet
 // forward, its backward and its weight gradient all use the ordinary row loaders.  grid = (ceil(T/32), KP/32, N)
-template <typename T>
-__global__ void __launch_bounds__(256) mel_pack_kernel(const float* x, T* xt, int mel, int T_, int KP) {
+// TI = float (the reference collater's dtype) or _Float16 (patterns are fp16 on disk: half the host-to-device bytes)
+template <typename T, typename TI>
+__global__ void __launch_bounds__(256) mel_pack_kernel(const TI* x, T* xt, int mel, int T_, int KP) {
     __shared__ float tile[32][33];
     const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32, n = blockIdx.z;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
     for (int r = ly; r < 32; r += 8) {
         const int k = k0 + r, t = t0 + lx;
-        tile[r][lx] = (k < mel && t < T_) ? x[((size_t)n * mel + k) * T_ + t] : 0.0f;
+        tile[r][lx] = (k < mel && t < T_) ? (float)x[((size_t)n * mel + k) * T_ + t] : 0.0f;
     }
     __syncthreads();
     for (int r = ly; r < 32; r += 8) {

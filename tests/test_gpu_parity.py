@@ -276,6 +276,36 @@ def test_error_behaviour(mods):
         e.sum().backward()      # eval forward keeps no activations / params need grad -> explicit error
 
 
+# ------------------------------------------------------------------------------------------ fp16 mel input (row f2)
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fp16_mel_input_is_bitwise_the_widened_input(mods, prec):
+    """ge2e_encoder_forward_mel16: patterns are fp16 on disk (Pattern_Generator.py:191-198); feeding the fp16 batch and
+    feeding its float32 widening (what Datasets.py:84 does on the host) must give the same bits, forward and backward."""
+    GE2E, GE2E_Loss = mods
+    x16 = torch.from_numpy(O.formula_mel(3, 12, 80, 77, logmel=True)).half().cuda()
+    outs = []
+    for x in (x16, x16.float()):
+        m, _, _ = build(GE2E, prec, 0.1)
+        m.train()
+        emb = m(x)
+        GE2E_Loss().cuda()(emb, 3).backward()
+        outs.append((emb.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    # weight gradients use fp32 atomics (summation order varies run to run): equal to rounding, not bitwise
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
+def test_device_prefetcher_order_and_values(mods):
+    from speaker_embedding_torch_amd.Datasets import DevicePrefetcher
+    batches = [(torch.full((4, 80, 32), float(i), dtype=torch.float16).pin_memory(), [f"s{i}"]) for i in range(5)]
+    got = list(DevicePrefetcher(batches, "cuda"))
+    assert len(got) == 5
+    for i, (feat, names) in enumerate(got):
+        assert feat.is_cuda and feat.dtype == torch.float16 and names == [f"s{i}"]
+        assert torch.equal(feat.cpu(), batches[i][0])
+
+
 # ------------------------------------------------------------------------------------------ kernel-path agreement
 _PATH_SCRIPT = r"""
 import sys, numpy as np, torch

@@ -70,6 +70,23 @@ def test_dataset_and_collaters(tmp_path):
     assert len(sub) == 2
 
 
+def test_half_collater_and_prefetcher_cpu(tmp_path):
+    """with half=True the batch keeps the on-disk float16 (same values as the float32 batch), and the
+    prefetcher is a pass-through without a GPU."""
+    make_patterns(str(tmp_path))
+    ds = Datasets.Dataset(str(tmp_path), "METADATA.PICKLE", pattern_per_speaker=3)
+    items = [ds[0], ds[3]]
+    np.random.seed(5); b32 = Datasets.Collater(60, 70)(items)
+    np.random.seed(5); b16 = Datasets.Collater(60, 70, half=True)(items)
+    assert b16.dtype == torch.float16 and b16.shape == b32.shape and torch.equal(b16.float(), b32)
+    np.random.seed(6); f32, s32 = Datasets.Inference_Collater(5, 64, 32)(items)
+    np.random.seed(6); f16, s16 = Datasets.Inference_Collater(5, 64, 32, half=True)(items)
+    assert f16.dtype == torch.float16 and torch.equal(f16.float(), f32) and s16 == s32
+    batches = [torch.full((2, 3), float(i)) for i in range(4)]
+    pre = Datasets.DevicePrefetcher(batches, "cpu")
+    assert len(pre) == 4 and all(torch.equal(a, b) for a, b in zip(pre, batches))
+
+
 def _dp_worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from speaker_embedding_torch_amd import distributed as D
