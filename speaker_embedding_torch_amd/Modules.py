@@ -309,3 +309,43 @@ class GE2E_Loss(torch.nn.Module):
     def forward(self, embeddings, pattern_per_speaker):
         """embeddings: [Batch, Emb_dim], speaker-major (Datasets.Collater order); returns a 0-d loss."""
         return _LossFn.apply(self, embeddings, int(pattern_per_speaker))
+
+
+class _GatherBatchFn(torch.autograd.Function):
+    """all-gather of the per-rank d-vectors (rank-major = speaker-major, every rank holds whole speakers).  Every rank then
+    computes the SAME global loss, so dL/d(e_local) needs no second collective: it is the local slice of the full
+    gradient, times `world` because the parameter gradients are averaged (not summed) across ranks afterwards."""
+
+    @staticmethod
+    def forward(ctx, emb, group):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        emb = emb.contiguous()
+        parts = [torch.empty_like(emb) for _ in range(world)]
+        dist.all_gather(parts, emb, group=group)
+        ctx.n, ctx.rank, ctx.world = emb.shape[0], rank, world
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, d_full):
+        return d_full[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n] * float(ctx.world), None
+
+
+class GE2E_Loss_Global(GE2E_Loss):
+    """SURVEY row f1 (opt-in, NOT the reference's semantics): one GE2E loss over the speakers of ALL ranks.  The
+    reference gives every rank its own speakers and a local loss (Train.py:90-99), so the softmax is only as wide as a
+    rank's batch; here the [N_local, Emb] d-vectors are all-gathered (world x 245 KB at 64 x 15) and the similarity
+    matrix spans world x Speaker centroids -- e.g. 8 ranks x 8 speakers keep the 64-wide softmax of the single-GPU
+    recipe while each rank encodes 1/8 of the utterances (strong scaling).  With the mean gradient all-reduce that
+    follows (distributed.GradSync) the parameter gradient equals the one a single process would compute on the
+    concatenated batch.  Returns the global loss (identical on every rank)."""
+
+    def __init__(self, init_weight=10.0, init_bias=-5.0, group=None):
+        super().__init__(init_weight, init_bias)
+        self.group = group
+
+    def forward(self, embeddings, pattern_per_speaker):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            embeddings = _GatherBatchFn.apply(embeddings, self.group)
+        return super().forward(embeddings, pattern_per_speaker)

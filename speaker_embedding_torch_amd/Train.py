@@ -29,7 +29,7 @@ from .Arg_Parser import Load_Hyper_Parameters
 from .Datasets import Collater, Dataset, DevicePrefetcher, Inference_Collater
 from .distributed import apply_gradient_allreduce, init_distributed, reduce_tensor
 from .Logger import Logger
-from .Modules import GE2E, GE2E_Loss
+from .Modules import GE2E, GE2E_Loss, GE2E_Loss_Global
 from .Optim import FusedClipAdamW
 
 logging.basicConfig(level=logging.INFO, stream=sys.stdout,
@@ -95,7 +95,9 @@ class Trainer:
     # -------------------------------------------------------------------------------------- model
     def Model_Generate(self):
         self.model = GE2E(self.hp, seed=1234 + self.gpu_id).to(self.device)
-        self.criterion = GE2E_Loss().to(self.device)
+        # optional key Train.Global_Batch_Loss (default off = the reference's per-rank loss)
+        global_loss = bool(getattr(self.hp.Train, "Global_Batch_Loss", False)) and self.num_gpus > 1
+        self.criterion = (GE2E_Loss_Global() if global_loss else GE2E_Loss()).to(self.device)
         # torch.optim.AdamW semantics and state_dict (incl. the default weight_decay 0.01 the reference ends up with,
         # Train.py:122-127), with clip_grad_norm_(Gradient_Norm) fused into the same two device launches
         self.optimizer = FusedClipAdamW(

@@ -2,6 +2,6 @@
 
 Host-side mirror of the reference's module layout: `Modules` (GE2E, GE2E_Loss), `distributed`,
 `Arg_Parser`, `Train` (Trainer), `Inference` (Inferencer)."""
-from .Modules import GE2E, GE2E_Loss  # noqa: F401
+from .Modules import GE2E, GE2E_Loss, GE2E_Loss_Global  # noqa: F401
 
 __version__ = "0.1.0"

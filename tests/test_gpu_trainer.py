@@ -164,6 +164,55 @@ def test_two_rank_data_parallel_gradient_mean(tmp_path):
     assert b0[0][0] + b0[0][1] == total and b0[-1][0] == 0
 
 
+def _global_loss_worker(rank, world, port, hp_path, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, REPO)
+    from speaker_embedding_torch_amd import distributed as D
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss_Global
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    hp = Load_Hyper_Parameters(hp_path)
+    torch.manual_seed(0)
+    model = GE2E(hp, precision="fp32", seed=7).cuda()
+    load_formula(model)
+    model = D.apply_gradient_allreduce(model)
+    model.train()
+    x_all = torch.from_numpy(O.formula_mel(31, 12, 80, 48, logmel=True))        # 4 speakers x 3 utterances, speaker-major
+    x = x_all[rank * 6:(rank + 1) * 6].cuda()                                     # this rank: 2 whole speakers
+    loss = GE2E_Loss_Global().cuda()(model(x), 3)
+    loss.backward()
+    torch.cuda.synchronize()
+    out[rank] = (loss.item(), torch.cat([p.grad.flatten() for p in model.parameters()]).cpu())
+    torch.distributed.destroy_process_group()
+
+
+def test_global_batch_loss_equals_single_process_on_the_concatenated_batch(tmp_path):
+    """2 ranks x 2 speakers with GE2E_Loss_Global + the mean gradient all-reduce == one process on
+    all 4 speakers (dropout 0, fp32 kernels): same loss, same parameter gradient."""
+    import torch.multiprocessing as mp
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    hp_path = write_hp(tmp_path, dropout=0.0)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_global_loss_worker, args=(2, 31600 + os.getpid() % 2000, hp_path, out), nprocs=2, join=True)
+        res = dict(out)
+    hp = Load_Hyper_Parameters(hp_path)
+    model = GE2E(hp, precision="fp32", seed=7).cuda()
+    load_formula(model)
+    model.train()
+    x_all = torch.from_numpy(O.formula_mel(31, 12, 80, 48, logmel=True)).cuda()
+    loss = GE2E_Loss().cuda()(model(x_all), 3)
+    loss.backward()
+    ref = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu()
+    for rank in (0, 1):
+        l, g = res[rank]
+        assert abs(l - loss.item()) < 1e-5
+        assert rel_l2(g.numpy(), ref.numpy()) < 1e-4
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_fused_clip_adamw_matches_torch():
     """FusedClipAdamW == clip_grad_norm_ + torch.optim.AdamW (reference Train.py:154-162), three steps, incl. state_dict."""
     from speaker_embedding_torch_amd.Optim import FusedClipAdamW
