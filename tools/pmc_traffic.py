@@ -12,7 +12,7 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
-    "gemm": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n) and not is_ln(n),
+    "gemm": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_ws_lnbwd_kernel" in n) and not is_ln(n),
     "gemm_ln": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_kl_kernel" in n) and is_ln(n),
     "wgrad": lambda n: "wgrad_kernel" in n,
     "attn_fwd": lambda n: "attn_fwd_kernel" in n,
