@@ -128,6 +128,18 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
                          float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int64_t step);
 
+/* wav -> log-mel front-end (reference meldataset.py:73-96 `mel_spectrogram`, used by Inference.py:71-81
+ * and Pattern_Generator.py:96-106): reflect-pad (n_fft - hop)/2, STFT with a periodic Hann window of n_fft samples
+ * (the reference's Frame_Length == N_FFT, center=False), magnitude sqrt(re^2 + im^2 + 1e-9), mel filterbank,
+ * log(clamp(., 1e-5)).
+ * wav:        device fp32 [batch, samples]         (zero-padded to a common length, as Pattern_Generator.Audio_Stack does)
+ * mel_basis:  device fp32 [n_mels, n_fft/2 + 1]    (librosa.filters.mel in the reference)
+ * out_logmel: device fp32 [batch, n_mels, ge2e_mel_frames()]  -- channels-first, the layout ge2e_encoder_forward reads */
+int ge2e_mel_frames(int samples, int n_fft, int hop);                       /* negative: unsupported geometry */
+size_t ge2e_mel_workspace_bytes(int batch, int samples, int n_fft, int hop, int n_mels);   /* 0: unsupported */
+int ge2e_mel_spectrogram(ge2e_handle h, void* stream, const float* wav, int batch, int samples, int n_fft, int hop, int n_mels,
+                         const float* mel_basis, float* out_logmel, void* workspace, size_t workspace_bytes);
+
 /* Live per-kernel timing for the roofline leg of bench.py.  While a class bit is enabled every launch of that
  * kernel class is bracketed by hipEvents ON THE LAUNCH STREAM; ge2e_profile_read() synchronises those events,
  * returns the summed duration, the summed algorithmic FLOPs, the summed algorithmic HBM bytes (operands in + tile

@@ -56,6 +56,10 @@ _SIG = {
     "ge2e_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
+    "ge2e_mel_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "ge2e_mel_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ge2e_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ge2e_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "ge2e_profile_read": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                     C.POINTER(C.c_int64)]),
@@ -165,6 +169,17 @@ class Handle:
     def clip_adamw_step(self, stream, ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, norm, max_norm, lr, b1, b2, eps, wd, step):
         self.check(self.lib.ge2e_clip_adamw_step(self._h, stream, len(ptrs_p), ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel,
                                                  norm.data_ptr(), max_norm, lr, b1, b2, eps, wd, step), "ge2e_clip_adamw_step")
+
+    def mel_frames(self, samples, n_fft, hop):
+        return self.lib.ge2e_mel_frames(samples, n_fft, hop)
+
+    def mel_workspace_bytes(self, batch, samples, n_fft, hop, n_mels):
+        return self.lib.ge2e_mel_workspace_bytes(batch, samples, n_fft, hop, n_mels)
+
+    def mel_spectrogram(self, stream, wav, n_fft, hop, n_mels, basis, out, ws):
+        b, l = wav.shape
+        self.check(self.lib.ge2e_mel_spectrogram(self._h, stream, wav.data_ptr(), b, l, n_fft, hop, n_mels, basis.data_ptr(),
+                                                 out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size()), "ge2e_mel_spectrogram")
 
     def profile_enable(self, mask):
         self.check(self.lib.ge2e_profile_enable(self._h, mask), "ge2e_profile_enable")

@@ -17,6 +17,7 @@
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
 #include "misc.cuh"
+#include "melfront.cuh"
 
 using namespace ge2e;
 
@@ -960,6 +961,60 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
 void* ge2e_bucket_stream(ge2e_handle h, void* stream) {
     if (!h || !h->overlap || !h->side) return stream;
     return (void*)h->side;
+}
+
+// ---- wav -> log-mel front-end (reference meldataset.py:73-96)
+namespace {
+struct MelLayout { int F, bins, n1, k2, rows; size_t W, A, S, Mg, P, Ml, total; };
+bool mel_layout(int batch, int samples, int n_fft, int hop, int n_mels, MelLayout& m) {
+    if (batch <= 0 || samples <= 0 || n_fft < 128 || n_fft % 32 != 0 || hop <= 0 || hop > n_fft || (n_fft - hop) % 2 != 0 || n_mels < 1 || n_mels > 128) return false;
+    const int pad = (n_fft - hop) / 2;
+    if (samples <= pad || samples + 2 * pad < n_fft) return false;           // reflect padding needs pad < samples
+    m.F = (samples + 2 * pad - n_fft) / hop + 1;
+    m.bins = n_fft / 2 + 1; m.n1 = (2 * m.bins + 127) / 128 * 128; m.k2 = (m.bins + 31) / 32 * 32; m.rows = batch * m.F;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    m.W = take((size_t)m.n1 * n_fft * 4); m.A = take((size_t)m.rows * n_fft * 4); m.S = take((size_t)m.rows * m.n1 * 4);
+    m.Mg = take((size_t)m.rows * m.k2 * 4); m.P = take((size_t)128 * m.k2 * 4); m.Ml = take((size_t)m.rows * 128 * 4);
+    m.total = off;
+    return true;
+}
+}  // namespace
+
+int ge2e_mel_frames(int samples, int n_fft, int hop) {
+    MelLayout m;
+    return mel_layout(1, samples, n_fft, hop, 1, m) ? m.F : GE2E_EINVAL;
+}
+size_t ge2e_mel_workspace_bytes(int batch, int samples, int n_fft, int hop, int n_mels) {
+    MelLayout m;
+    return mel_layout(batch, samples, n_fft, hop, n_mels, m) ? m.total : 0;
+}
+int ge2e_mel_spectrogram(ge2e_handle h, void* stream, const float* wav, int batch, int samples, int n_fft, int hop, int n_mels,
+                         const float* mel_basis, float* out_logmel, void* workspace, size_t workspace_bytes) {
+    if (!h) return GE2E_EINVAL;
+    if (!wav || !mel_basis || !out_logmel || !workspace) return fail(h, GE2E_EINVAL, "null pointer argument");
+    MelLayout m;
+    if (!mel_layout(batch, samples, n_fft, hop, n_mels, m)) return fail(h, GE2E_EUNSUPPORTED, "mel front-end: unsupported n_fft / hop / n_mels / length");
+    if (workspace_bytes < m.total) return fail(h, GE2E_EINVAL, "mel front-end: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace;
+    const int pad = (n_fft - hop) / 2;
+    GE2E_LAUNCH(h, dft_basis_kernel, dim3(m.n1), dim3(256), 0, st, (float*)(ws + m.W), n_fft, m.bins, m.n1);
+    GE2E_LAUNCH(h, pad_basis_kernel, dim3(128), dim3(256), 0, st, mel_basis, (float*)(ws + m.P), n_mels, m.bins, m.k2);
+    GE2E_LAUNCH(h, frame_window_kernel, dim3(m.rows), dim3(256), 0, st, wav, (float*)(ws + m.A), samples, m.F, n_fft, hop, pad);
+    {
+        GemmArgs a{};
+        a.A = ws + m.A; a.lda = n_fft; a.W = ws + m.W; a.ldw = n_fft; a.C = ws + m.S; a.ldc = m.n1; a.M = m.rows; a.N = m.n1; a.K = n_fft;
+        CK((launch_gemm<float, 128, 128, 64, 64, EPI_NONE, ALOAD_ROW, 2>(h, st, a)));
+    }
+    GE2E_LAUNCH(h, mag_kernel, dim3(m.rows), dim3(256), 0, st, (const float*)(ws + m.S), m.n1, (float*)(ws + m.Mg), m.k2, m.bins, m.rows);
+    {
+        GemmArgs a{};
+        a.A = ws + m.Mg; a.lda = m.k2; a.W = ws + m.P; a.ldw = m.k2; a.C = ws + m.Ml; a.ldc = 128; a.M = m.rows; a.N = 128; a.K = m.k2;
+        CK((launch_gemm<float, 128, 128, 64, 64, EPI_NONE, ALOAD_ROW, 2>(h, st, a)));
+    }
+    GE2E_LAUNCH(h, logmel_kernel, dim3((m.F + 31) / 32, batch), dim3(256), 0, st, (const float*)(ws + m.Ml), out_logmel, m.F, n_mels);
+    return 0;
 }
 
 int ge2e_profile_enable(ge2e_handle h, int class_mask) {
