@@ -320,7 +320,9 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     const int tn = a.N / 128, tk = (a.K + 127) / 128;
     // row slices: enough blocks for ~2 per CU, few enough that the fp32 partial tiles (one 64 KB atomic flush per
     // block) stay small next to the operand traffic
-    int splits = (512 + tn * tk - 1) / (tn * tk);
+    // never more than the 512 blocks that are resident at once (2 per CU): in_proj's 12 tiles x 43 slices = 516 blocks ran the
+    // last 4 alone in a second wave, 163 us instead of 125
+    int splits = std::max(1, 512 / (tn * tk));
     const int max_splits = (a.R + 4 * RS - 1) / (4 * RS);
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -20,7 +20,7 @@ int main() {
     CHECK(hipMalloc(&dW, 1024 * 1024 * 4)); CHECK(hipMalloc(&dW2, 1024 * 1024 * 4)); CHECK(hipMalloc(&db, 4096)); CHECK(hipMalloc(&db2, 4096));
     fill_bf16<<<2048, 256>>>(Y, (size_t)R * 1024, 1); fill_bf16<<<2048, 256>>>(X, (size_t)R * 1024, 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    struct S { const char* name; int N, K; } shapes[] = {{"l1 N1024 K256", 1024, 256}, {"l2 N256 K1024", 256, 1024}, {"in N768 K256", 768, 256}, {"out N256 K256", 256, 256}};
+    struct S { const char* name; int N, K, ldy; } shapes[] = {{"l1 N1024 K256", 1024, 256, 1024}, {"l2 N256 K1024", 256, 1024, 256}, {"in N768 K256", 768, 256, 768}, {"in N768 ldy1024", 768, 256, 1024}, {"in N768 ldy896", 768, 256, 896}, {"kv N512 ldy768", 512, 256, 768}, {"out N256 K256", 256, 256, 256}};
     for (auto& sh : shapes) {
         const double fl = 2.0 * R * sh.N * sh.K, by = 2.0 * R * (sh.N + sh.K);
         float ms;
@@ -29,9 +29,9 @@ int main() {
             auto kern = wgrad_kernel<T, ALOAD_ROW, 3, 2>;
             const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
             CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            WgradArgs a{}; a.Y = Y; a.ldy = sh.N; a.X = X; a.ldx = sh.K; a.dW = dW; a.ldw = sh.K; a.db = db; a.R = R; a.N = sh.N; a.K = sh.K;
+            WgradArgs a{}; a.Y = Y; a.ldy = sh.ldy; a.X = X; a.ldx = sh.K; a.dW = dW; a.ldw = sh.K; a.db = db; a.R = R; a.N = sh.N; a.K = sh.K;
             const int tn = sh.N / 128, tk = sh.K / 128;
-            int splits = (512 + tn * tk - 1) / (tn * tk); int rps = (R + splits - 1) / splits; rps = (rps + RS - 1) / RS * RS; splits = (R + rps - 1) / rps;
+            int splits = std::max(1, 512 / (tn * tk)); int rps = (R + splits - 1) / splits; rps = (rps + RS - 1) / RS * RS; splits = (R + rps - 1) / rps;
             a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
             for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(256), smem, 0, a);
             hipEventRecord(e0); for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(kern, dim3(tn * tk * splits), dim3(256), smem, 0, a); hipEventRecord(e1); hipEventSynchronize(e1);
@@ -44,7 +44,7 @@ int main() {
             auto kern = wgrad256_kernel;
             const size_t smem = wgrad256_smem();
             CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            WgradArgs a{}; a.Y = Y; a.ldy = sh.N; a.X = X; a.ldx = sh.K; a.dW = dW2; a.ldw = sh.K; a.db = db2; a.R = R; a.N = sh.N; a.K = sh.K;
+            WgradArgs a{}; a.Y = Y; a.ldy = sh.ldy; a.X = X; a.ldx = sh.K; a.dW = dW2; a.ldw = sh.K; a.db = db2; a.R = R; a.N = sh.N; a.K = sh.K;
             const int tn = sh.N / 256, tk = sh.K / 256;
             int splits = std::max(1, target / (tn * tk)); int rps = (R + splits - 1) / splits; rps = (rps + 31) / 32 * 32; splits = (R + rps - 1) / rps;
             a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
