@@ -354,7 +354,10 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
         const size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 ? (size_t)TP * (TP / 32) * 4 : 0);
-        auto kern = attn_bwd_kernel<T, KT, PAD>;
+        // scheduling-barrier spacing must not exceed the tile-group count of the loops it paces (KT groups in bf16): with the
+        // default 5 the short-T instances (KT <= 4) never hit a barrier, hipcc hoisted every fragment load, 247-256 VGPRs + spills
+        constexpr int SBE = KT >= 5 ? 5 : (KT >= 2 ? 2 : 1);
+        auto kern = attn_bwd_kernel<T, KT, PAD, SBE>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     }
     return 0;
