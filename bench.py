@@ -243,7 +243,7 @@ def main():
             hbm_bound = ai < ridge                              # which roof is lower at this arithmetic intensity
             roofline = {
                 "bound": "hbm" if hbm_bound else "mfma",
-                "kernel": {"gemm": "projection GEMM class: gemm_ws_kernel (K=256) + gemm_nt_kernel<128x128>", "gemm_ln": "LayerNorm GEMMs: gemm_ws_kernel<LN> + gemm_kl_kernel<LN>", "wgrad": "wgrad_kernel",
+                "kernel": {"gemm": "projection GEMM class: gemm_ws_kernel / gemm_ws_lnbwd_kernel (K=256) + gemm_nt_kernel<128x128>", "gemm_ln": "LayerNorm GEMMs: gemm_ws_kernel<LN> + gemm_kl_kernel<LN>", "wgrad": "wgrad_kernel",
                            "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
                 "achieved": round(gbs if hbm_bound else tf, 2), "peak": HBM_PEAK_GBS if hbm_bound else PEAK[args.precision],
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Soak test (development tool): many training steps on changing shapes, looking for hangs, faults and non-finite values.
+    timeout -k 10 600 python tools/soak.py [--steps 1500] [--shapes 150]
+Phase 1: the benchmark shape, `--steps` consecutive Train_Steps (dropout stream advances every step).
+Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16 and fp32 alternating, fresh NaN-poisoned workspace,
+one forward + backward + optimizer step each; every gradient must be finite."""
+import argparse, os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+from speaker_embedding_torch_amd.Optim import FusedClipAdamW
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=1500); ap.add_argument("--shapes", type=int, default=150)
+    args = ap.parse_args()
+    hp = bench.Load_Hyper_Parameters(os.path.join(bench.REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
+    dev = torch.device("cuda")
+    model = GE2E(hp, precision="bf16", seed=1).to(dev); crit = GE2E_Loss().to(dev)
+    opt = FusedClipAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)
+    model.train()
+    xs = [bench.synth_mel(960, 80, 160, 10 + i, dev) for i in range(4)]
+    t0 = time.time()
+    for i in range(args.steps):
+        loss = crit(model(xs[i & 3]), 15); opt.zero_grad(); loss.backward(); opt.step()
+        if i % 250 == 249:
+            print(f"phase 1 step {i + 1}: loss {loss.item():.4f} ({time.time() - t0:.1f} s)", flush=True)
+            assert np.isfinite(loss.item())
+    rng = np.random.default_rng(0)
+    for k in range(args.shapes):
+        S = int(rng.integers(2, 9)); P = int(rng.integers(2, 7)); T = int(rng.integers(17, 289)); prec = "bf16" if k % 2 == 0 else "fp32"
+        m = GE2E(hp, precision=prec, seed=k).to(dev); m._poison = True; m.train()
+        o = FusedClipAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)
+        x = bench.synth_mel(S * P, 80, T, 100 + k, dev)
+        loss = crit(m(x), P); o.zero_grad(); loss.backward(); o.step()
+        ok = np.isfinite(loss.item()) and all(torch.isfinite(p.grad).all().item() for p in m.parameters())
+        if not ok or k % 25 == 24:
+            print(f"phase 2 shape {k + 1}: S={S} P={P} T={T} {prec} loss {loss.item():.4f} finite={ok}", flush=True)
+        assert ok, (S, P, T, prec)
+    print("soak ok")
+
+
+if __name__ == "__main__":
+    main()
