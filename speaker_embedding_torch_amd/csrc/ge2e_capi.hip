@@ -566,11 +566,9 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         a.eps = c.ln_eps;
         a.xhat = (float*)(ws + L.xhat_f); a.rstd = (float*)(ws + L.rstd_f);
         a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm);
-        a.emb = (float*)(ws + L.emb_keep);
+        a.emb = (float*)(ws + L.emb_keep); a.emb_out = out_emb;       // both copies from the one kernel (no device-to-device copy)
         auto kern = tail_fwd_kernel<T>;
         GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
-        hipError_t e = hipMemcpyAsync(out_emb, ws + L.emb_keep, (size_t)(n / samples) * d * 4, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return fail_hip(h, e, "copy embeddings");
     }
     return 0;
 }

@@ -151,6 +151,7 @@ struct TailArgs {
     float* xhat; float* rstd;    // [N,256], [N]   saved for backward
     float* zm; float* nrm;       // [N/samples,256], [N/samples]
     float* emb;                  // [N/samples,256] output (also kept for backward)
+    float* emb_out;              // forward: the caller's copy of emb (written by the same kernel), or null
     // backward
     const float* d_emb; float* d_raw; void* dH;      // dH: [N*T,256] of T, only rows t=0 written
     float* dgf; float* dbf; float* dwq; float* dbq;
@@ -181,6 +182,7 @@ __global__ void __launch_bounds__(256) tail_fwd_kernel(const TailArgs p) {
     for (int k = 0; k < 256; ++k) e += zs[k] * p.wqT[k * 256 + c];
     const float nn = fmaxf(sqrtf(block256_sum(e * e, red)), 1e-12f);
     p.emb[(size_t)m * 256 + c] = e / nn;
+    if (p.emb_out) p.emb_out[(size_t)m * 256 + c] = e / nn;
     if (c == 0 && p.nrm) p.nrm[m] = nn;
 }
 
