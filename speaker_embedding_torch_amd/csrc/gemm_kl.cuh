@@ -1,5 +1,7 @@
-// Streaming k-loop GEMM for the wide-K, 256-column products (bf16 mode): FFN2 + LayerNorm (K = 1024), dHb = dF.W1
-// (K = 1024) and dHa = dQKV.Wqkv (K = 768), both with an addend tile.
+// Streaming k-loop GEMM for the wide-K, 256-column products (bf16 mode).  In the library it runs FFN2 + LayerNorm
+// (K = 1024, forward); the addend epilogue (EPI_ADD: dHb = dP + dF.W1 with K = 1024, dHa = dP + dQKV.Wqkv with K = 768) is
+// kept for tools/gemm_bench.hip -- alone it ties the tiled kernel (131 / 107 vs 136 / 109 us) and it needs a whole CU's
+// LDS, which the backward cannot give it beside the weight gradients.
 //
 //   C[M, 256] = epilogue(A[M, K] . W[256, K]^T  (+ R[M, 256]))
 //
