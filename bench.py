@@ -2,7 +2,10 @@
 """bench.py -- utterances/sec of one GE2E training step on the HIP path (BASELINE.json's metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+N > 1 works both ways: under a launcher (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+127.0.0.1 ... bench.py --gpus N ...`, RANK / WORLD_SIZE in the environment) or plain -- then this process, BEFORE it
+touches the GPU, starts that launcher itself as a fresh child (one rank per GPU over RCCL, as reference multi_gpu.sh:2
+does with torch.distributed.launch), relays rank 0's JSON line and exits with the child's code.
 
 A "step" is one full Trainer.Train_Step of the reference (Train.py:140-168) on one synthetic batch per
 rank: forward -> GE2E loss -> backward (bucketed RCCL gradient mean overlapped with it when N > 1)
@@ -12,8 +15,9 @@ on, bf16 storage / fp32 accumulate.  Inputs are generated on the device before t
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     live hipEvent timing of the dominant kernel class (projection GEMMs) inside the timed region
-  "cpu_baseline": the CPU oracle (numpy port of the reference's Device '-1' path) timed on this box's host
-                  cores on a bounded sample of the same workload (N = 1, rank 0 only).
+  "cpu_baseline": a PyTorch-CPU restatement of the same Train_Step (oracle/torch_restatement.py: what the reference's
+                  Device '-1' path executes) timed on this box's host cores on the FULL batch, 1 warm-up + 3 steps,
+                  best-of (N = 1, rank 0 only).
 """
 import argparse
 import json
@@ -31,7 +35,8 @@ from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters  # noqa
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
 from speaker_embedding_torch_amd.Optim import FusedClipAdamW  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+DTYPE_NAME = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}
 HBM_PEAK_GBS = 8000.0                             # HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
                     "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD}
@@ -56,49 +61,83 @@ def load_pmc_traffic(kernel):
     return best
 
 
-def cpu_baseline(speakers, utts, frames, mel, budget_speakers=4, steps=2):
-    """Times the oracle's Train_Step (fwd + loss + bwd + clip + AdamW, dropout on) on the host cores."""
-    import numpy as np
-    from oracle import ge2e_oracle as O      # checker / baseline only -- never on the product path
-    sp = min(speakers, budget_speakers)
-    params = O.formula_params()
-    x = O.formula_mel(7, sp * utts, mel, frames, logmel=True)
-    state = {}
-    O.train_step(params, x[: utts * 2], utts, state)          # warm-up (BLAS threads, page-in)
-    t0 = time.perf_counter()
-    for s in range(steps):
-        O.train_step(params, x, utts, state, seed=1234, step=s)
-    dt = (time.perf_counter() - t0) / steps
+def cpu_baseline(speakers, utts, frames, mel, steps=3):
+    """the reference's CPU path restated with stock torch.nn operators (oracle/torch_restatement.py,
+    pinned against the reference's golden vectors), full batch, fp32, dropout on, clip + AdamW, threads = the physical
+    cores this job may use, 1 warm-up + `steps` steps, best-of."""
+    from oracle import torch_restatement as TR      # checker / baseline only -- never on the product path
+    before = torch.get_num_threads()
     try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    return {"value": round(sp * utts / dt, 2), "unit": "utterances/sec", "cores": int(cores), "kind": "port",
-            "sample": f"{steps} Train_Steps of {sp} spk x {utts} utt x {frames} fr x {mel} mel "
-                      f"({sp * utts} of the {speakers * utts} utterances of one step), numpy fp32 oracle, dropout on"}
+        best, done, threads = TR.time_train_steps(speakers, utts, frames, mel, steps=steps)
+    finally:
+        torch.set_num_threads(before)
+    return {"value": round(speakers * utts / best, 2), "unit": "utterances/sec", "cores": int(threads), "kind": "port",
+            "sample": f"full Train_Step of {speakers} spk x {utts} utt x {frames} fr x {mel} mel ({speakers * utts} utterances), "
+                      f"torch-CPU restatement of the reference's Device '-1' path, fp32, dropout on, clip + AdamW; "
+                      f"1 warm-up + {done} steps, best {best:.2f} s/step"}
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n, argv):
+    """--gpus N > 1 without a launcher: start `torch.distributed.run` with N ranks as a FRESH child process (never an
+    exec, and before this process has made any GPU call), relay the ranks' single JSON line, return the child's code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in js:
+            print(ln, file=sys.stderr)
+    if js:
+        print(js[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks printed no JSON line", file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+def dry_launch(rank, world, emit):
+    """--dry-launch: rendezvous of the ranks over gloo on the CPU (what the N > 1 path needs from the launcher, minus the
+    GPUs): every rank contributes its rank to an all-reduce; rank 0 prints the JSON line."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        ok = int(t.item()) == world * (world - 1) // 2
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ok = True
+    print(f"dry-launch rank {rank} / world {world}", file=sys.stderr)
+    if rank == 0:
+        emit({"dry_launch": True, "ok": bool(ok), "n_gpus": world, "config": {"parallelism": f"dp{world}" if world > 1 else "single"}})
+    return 0 if ok else 1
 
 
 def main():
-    # Contract: rank 0 prints exactly ONE line (the JSON) on stdout.  Libraries chat on fd 1 too (RCCL prints a version
-    # banner at communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON line is written
-    # to the saved, real stdout at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
-
-    def emit(obj):
-        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
-
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--speakers", type=int, default=None)
     ap.add_argument("--utts", type=int, default=None)
     ap.add_argument("--frames", type=int, default=160)
-    ap.add_argument("--roofline-kernel", default="gemm", choices=sorted(ROOFLINE_CLASSES))
+    ap.add_argument("--roofline-kernel", default="wgrad", choices=sorted(ROOFLINE_CLASSES))
     ap.add_argument("--mode", default="train", choices=["train", "infer"],
                     help="infer: BASELINE.json configs[3] style embed-only run (eval forward, --samples slices per utterance)")
     ap.add_argument("--samples", type=int, default=5)
@@ -110,15 +149,36 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-every", type=int, default=4, help="profile the roofline kernel class on every N-th timed step")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="only start the ranks, rendezvous over gloo on the CPU and print rank / world (tests the N > 1 launch path)")
     ap.add_argument("-hp", "--hyper_parameters", default=os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # ---- N > 1 without a launcher: become the launcher (no GPU call has been made in this process)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        if not args.dry_launch and torch.cuda.device_count() < args.gpus:      # device_count() does not initialise the GPU
+            raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible on this node")
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+
+    # Contract: rank 0 prints exactly ONE line (the JSON) on stdout.  Libraries chat on fd 1 too (RCCL prints a version
+    # banner at communicator creation), so fd 1 is pointed at stderr for the whole run and the JSON line is written
+    # to the saved, real stdout at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_launch:
+        sys.exit(dry_launch(rank, world, emit))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GE2E hot path has no CPU fallback")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -160,7 +220,7 @@ def main():
             dt = time.perf_counter() - t0
         emit({"metric": "utterances/sec, embed-only (eval forward)", "value": round(n_utt * args.steps / dt, 1),
                           "unit": "utterances/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": "bf16" if args.precision == "bf16" else "f32",
+                          "ms_per_step": round(dt / args.steps * 1e3, 3), "dtype": DTYPE_NAME[args.precision],
                           "data": "synthetic", "config": {"workload": f"{n_utt} utt x {args.samples} slices x {T} fr x {mel} mel, "
                                                                       f"d-vectors [{n_utt}, 256]"},
               "unit_norm_err": float((e.norm(dim=1) - 1).abs().max())})
@@ -262,7 +322,7 @@ def main():
             "value": round(S * P * world * args.steps / dt, 1), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "input": args.input + ("+prefetch" if (args.prefetch and args.input != "resident") else ""),
             "config": {"workload": f"{S} spk x {P} utt x {T} fr x {mel} mel per GPU, full Train_Step "
                                    f"(fwd+GE2E loss+bwd+clip+AdamW), dropout 0.1, random-init weights",

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GE2E_ABI_VERSION 1
+#define GE2E_ABI_VERSION 2
 
 enum {
     GE2E_OK = 0,
@@ -34,7 +34,11 @@ enum {
     GE2E_EWORKSPACE = -3     /* workspace too small */
 };
 
-enum { GE2E_PREC_F32 = 0, GE2E_PREC_BF16 = 1 };
+/* Arithmetic modes.  F32: fp32 MFMA (exact fma chains; the parity path, reference `Use_Mixed_Precision: false`).
+ * BF16 / F16: activations and activation gradients stored in 16 bits, fp32 accumulation, fp32 master weights, fp32
+ * parameter gradients.  F16 is what the reference's own mixed precision is (torch.cuda.amp.autocast + GradScaler,
+ * Train.py:134,145,153-162): its gradients need the loss scaling of ge2e_clip_adamw_step_scaled; BF16 does not. */
+enum { GE2E_PREC_F32 = 0, GE2E_PREC_BF16 = 1, GE2E_PREC_F16 = 2 };
 
 /* Mirrors the `Sound.Mel_Dim` / `GE2E.*` block of Hyper_Parameters.yaml:1-18 plus the arithmetic mode. */
 typedef struct ge2e_config {
@@ -47,12 +51,15 @@ typedef struct ge2e_config {
     float pe_dropout;        /* GE2E.Positional_Encoding.Dropout_Rate                */
     float tf_dropout;        /* GE2E.Transformer.Dropout_Rate                        */
     float ln_eps;            /* torch LayerNorm default 1e-5                         */
-    int32_t precision;       /* GE2E_PREC_F32: fp32 MFMA (parity path); GE2E_PREC_BF16: bf16 storage, fp32 accumulate */
+    int32_t precision;       /* GE2E_PREC_F32 / GE2E_PREC_BF16 / GE2E_PREC_F16 */
 } ge2e_config;
 
 typedef struct ge2e_handle_s* ge2e_handle;
 
 int ge2e_abi_version(void);
+/* SHA-256 prefix of the sources this binary was compiled from (speaker_embedding_torch_amd/_build.py): the loader refuses
+ * a library that does not match the csrc/ it sits beside. */
+const char* ge2e_source_hash(void);
 int ge2e_create(const ge2e_config* cfg, ge2e_handle* out);     /* no GPU call is made here */
 int ge2e_destroy(ge2e_handle h);
 const char* ge2e_last_error(ge2e_handle h);
@@ -127,6 +134,19 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
                          float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
                          float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
                          float weight_decay, int64_t step);
+
+/* The same step under mixed-precision loss scaling, with NO host synchronisation (replaces GradScaler.unscale_ /
+ * clip_grad_norm_ / GradScaler.step / GradScaler.update of reference Train.py:154-162).  `grads` hold scale x the true
+ * gradient (the caller multiplied the loss by scaler_state[0] before backward, as GradScaler.scale does).
+ * scaler_state: device fp32[4] = { scale, growth_tracker, found_inf of the last call (0/1), AdamW steps taken so far }.
+ * If any gradient is inf / nan the parameters, moments and step count stay untouched and scale *= backoff_factor;
+ * otherwise gradients are unscaled in place, clipped, applied (bias correction from the DEVICE step count), and after
+ * growth_interval clean steps in a row scale *= growth_factor  (torch.cuda.amp.GradScaler semantics). */
+int ge2e_clip_adamw_step_scaled(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                                float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float* scaler_state, float growth_factor, float backoff_factor,
+                                int growth_interval);
 
 /* wav -> log-mel front-end (reference meldataset.py:73-96 `mel_spectrogram`, used by Inference.py:71-81
  * and Pattern_Generator.py:96-106): reflect-pad (n_fft - hop)/2, STFT with a periodic Hann window of n_fft samples

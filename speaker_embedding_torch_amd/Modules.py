@@ -139,8 +139,9 @@ class _EncoderFn(torch.autograd.Function):
         ws = module._workspace(n, t, train, token)
         out = torch.empty(n // samples, hnd.cfg.emb, device=features.device, dtype=torch.float32)
         seed, step = module.seed, module._step
-        stream = torch.cuda.current_stream(features.device).cuda_stream
-        hnd.encoder_forward(stream, features, n, t, samples, ptrs, module.positional_encoding.pe, out, ws, train, seed, step)
+        with torch.cuda.device(features.device):      # the library launches on (and creates its side stream for) the CURRENT device
+            stream = torch.cuda.current_stream(features.device).cuda_stream
+            hnd.encoder_forward(stream, features, n, t, samples, ptrs, module.positional_encoding.pe, out, ws, train, seed, step)
         if train:
             module._step += 1
         ctx.module, ctx.ws, ctx.train, ctx.token = module, ws, train, token
@@ -160,23 +161,33 @@ class _EncoderFn(torch.autograd.Function):
         ptrs = hnd.ptr_table(plist)
         d_emb = d_emb.contiguous().float()
         grads = torch.empty(hnd.param_total, device=features.device, dtype=torch.float32)
-        stream = torch.cuda.current_stream(features.device).cuda_stream
-        sync = module._grad_sync
-        cb = sync.bucket_callback(grads, hnd, stream) if sync is not None else None
-        hnd.encoder_backward(stream, features, n, t, samples, ptrs, d_emb, grads, ctx.ws, seed, step, cb)
-        if sync is not None:
-            sync.finish(grads)
+        with torch.cuda.device(features.device):      # backward runs on the autograd thread: make the tensors' device current there too
+            stream = torch.cuda.current_stream(features.device).cuda_stream
+            sync = module._grad_sync
+            cb = sync.bucket_callback(grads, hnd, stream) if sync is not None else None
+            hnd.encoder_backward(stream, features, n, t, samples, ptrs, d_emb, grads, ctx.ws, seed, step, cb)
+            if sync is not None:
+                sync.finish(grads)
         if ctx.token is not None:
             ctx.token.done = True
         out = [grads[o:o + k].view_as(p) for o, k, p in zip(hnd.param_offset, hnd.param_numel, params)]
         return (None, None, None, *out)
 
 
+def default_precision(hp):
+    """Arithmetic mode a hyper-parameter file asks for (reference Train.py:134,145; see GE2E.__doc__)."""
+    if not getattr(hp, "Use_Mixed_Precision", False):
+        return "fp32"
+    return str(getattr(hp, "Mixed_Precision_Dtype", "fp16")).lower().replace("float16", "fp16").replace("bfloat16", "bf16")
+
+
 class GE2E(torch.nn.Module):
     """Speaker encoder of reference Modules.py:5-59 on the HIP path.
 
-    `precision`: 'fp32' (fp32 MFMA; d-vectors within 1e-4 of the reference CPU path) or 'bf16'
-    (bf16 storage / fp32 accumulate).  Default follows `hp.Use_Mixed_Precision` like Train.py:134,145.
+    `precision`: 'fp32' (fp32 MFMA; d-vectors within 1e-4 of the reference CPU path), 'bf16' or 'fp16' (16-bit
+    storage / fp32 accumulate; fp16 is the reference's own mixed precision and wants the GradScaler of Optim.py).
+    Default follows `hp.Use_Mixed_Precision` like Train.py:134,145: false -> 'fp32'; true -> the optional key
+    `hp.Mixed_Precision_Dtype` ('bf16' | 'fp16'), 'fp16' when the key is absent (what autocast means in the reference).
     """
 
     def __init__(self, hyper_parameters: Namespace, precision=None, seed=0):
@@ -190,9 +201,9 @@ class GE2E(torch.nn.Module):
         self.transformer = _Transformer(d, d * 4, self.hp.GE2E.Transformer.Num_Layers)
         self.projection = Conv1d(d, d, w_init_gain="linear")
         if precision is None:
-            precision = "bf16" if getattr(self.hp, "Use_Mixed_Precision", False) else "fp32"
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
+            precision = default_precision(self.hp)
+        if precision not in _lib.PRECISIONS:
+            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
         self.precision = precision
         self.seed = int(seed)
         self._step = 0
@@ -204,7 +215,10 @@ class GE2E(torch.nn.Module):
 
     # -- plumbing ------------------------------------------------------------------------------
     def _handle(self):
-        h = self._handles.get(self.precision)
+        # one handle per (arithmetic mode, device): a handle's side stream and fence events belong to one device
+        dev = self.prenet.weight.device
+        hkey = (self.precision, dev.index if dev.type == "cuda" else -1)
+        h = self._handles.get(hkey)
         if h is None:
             g = self.hp.GE2E
             h = _lib.Handle(
@@ -212,11 +226,11 @@ class GE2E(torch.nn.Module):
                 layers=g.Transformer.Num_Layers, ffn=g.Embedding_Size * 4,
                 max_position=g.Positional_Encoding.Max_Position,
                 pe_dropout=g.Positional_Encoding.Dropout_Rate, tf_dropout=g.Transformer.Dropout_Rate,
-                ln_eps=1e-5, precision=_lib.PREC_BF16 if self.precision == "bf16" else _lib.PREC_F32)
+                ln_eps=1e-5, precision=_lib.PRECISIONS[self.precision])
             names = [n for n, _ in self.named_parameters()]
             if names != h.param_names:
                 raise RuntimeError("parameter table of libge2e_hip.so differs from the module's state_dict keys")
-            self._handles[self.precision] = h
+            self._handles[hkey] = h
         return h
 
     def _workspace(self, n, t, train, token=None):
@@ -242,7 +256,7 @@ class GE2E(torch.nn.Module):
         """Diagnostics for the parity tests: a typed view of a named intermediate of the last forward."""
         off, size = self._handle().debug_tap(name, n, t, train)
         ws = self._ws[(bool(train), self.precision)]
-        dt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[self.precision]
         return ws[off:off + size].view(dt)
 
     # -- reference API -------------------------------------------------------------------------
@@ -259,13 +273,14 @@ class _LossFn(torch.autograd.Function):
         n, d = emb.shape
         if n % pattern_per_speaker != 0:
             raise RuntimeError("batch is not a multiple of pattern_per_speaker")
-        hnd = module._handle(d)
+        hnd = module._handle(d, emb.device)
         speakers = n // pattern_per_speaker
         ws = torch.empty(hnd.loss_workspace_bytes(speakers, pattern_per_speaker), dtype=torch.uint8, device=emb.device)
         loss = torch.empty(1, device=emb.device, dtype=torch.float32)
         w, b = module._scalars()
-        stream = torch.cuda.current_stream(emb.device).cuda_stream
-        hnd.loss_forward(stream, emb, speakers, pattern_per_speaker, w, b, loss, ws)
+        with torch.cuda.device(emb.device):
+            stream = torch.cuda.current_stream(emb.device).cuda_stream
+            hnd.loss_forward(stream, emb, speakers, pattern_per_speaker, w, b, loss, ws)
         ctx.module, ctx.ws, ctx.dims = module, ws, (speakers, pattern_per_speaker, w, b)
         ctx.save_for_backward(emb)
         return loss.reshape(())
@@ -274,10 +289,11 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, d_loss):
         (emb,) = ctx.saved_tensors
         speakers, utts, w, b = ctx.dims
-        hnd = ctx.module._handle(emb.shape[1])
+        hnd = ctx.module._handle(emb.shape[1], emb.device)
         d_emb = torch.empty_like(emb)
-        stream = torch.cuda.current_stream(emb.device).cuda_stream
-        hnd.loss_backward(stream, emb, speakers, utts, w, b, d_loss.reshape(1).contiguous().float(), d_emb, ctx.ws)
+        with torch.cuda.device(emb.device):
+            stream = torch.cuda.current_stream(emb.device).cuda_stream
+            hnd.loss_backward(stream, emb, speakers, utts, w, b, d_loss.reshape(1).contiguous().float(), d_emb, ctx.ws)
         return None, d_emb, None
 
 
@@ -294,6 +310,7 @@ class GE2E_Loss(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.tensor(float(init_bias)))
         self._cache = None
         self._hnd = None
+        self._hnd_key = None
 
     def _scalars(self):
         ver = (self.weight._version, self.bias._version, self.weight.data_ptr(), self.bias.data_ptr())
@@ -301,9 +318,11 @@ class GE2E_Loss(torch.nn.Module):
             self._cache = (ver, float(self.weight.detach()), float(self.bias.detach()))   # host read only when changed
         return self._cache[1], self._cache[2]
 
-    def _handle(self, emb):
-        if self._hnd is None or self._hnd.cfg.emb != emb:
-            self._hnd = _lib.Handle(emb=emb, heads=emb // 64)
+    def _handle(self, emb, device):
+        # one handle per device: a handle's streams / events belong to the device of its first call
+        key = (emb, device.index if device.type == "cuda" else -1)
+        if self._hnd is None or self._hnd_key != key:
+            self._hnd, self._hnd_key = _lib.Handle(emb=emb, heads=emb // 64), key
         return self._hnd
 
     def forward(self, embeddings, pattern_per_speaker):

@@ -6,10 +6,12 @@ with the reference's state_dict keys, auto-resume from the newest checkpoint, th
 the CLI `python -m speaker_embedding_torch_amd.Train -hp <yaml> [-s steps]`.
 
 What differs, deliberately:
-  * model + loss run in libge2e_hip.so (no torch fallback); `Use_Mixed_Precision: true` selects the bf16-storage
-    kernels (no GradScaler: bf16 keeps fp32's exponent range), false the fp32 MFMA kernels;
-  * multi-GPU = one process per GPU under torchrun; gradients are averaged bucket by bucket over RCCL while
-    backward is still running (distributed.py) instead of one all-reduce after it;
+  * model + loss run in libge2e_hip.so (no torch fallback); `Use_Mixed_Precision: false` selects the fp32 MFMA kernels,
+    true the 16-bit-storage kernels: float16 with dynamic loss scaling as in the reference (Train.py:134,145,153-162;
+    `Optim.GradScaler`, device-side) or -- optional key `Mixed_Precision_Dtype: 'bf16'` -- bfloat16, which needs no scaler;
+  * multi-GPU = one process per GPU; gradients are averaged bucket by bucket over RCCL while backward is still running
+    (distributed.py) instead of one all-reduce after it.  `python -m speaker_embedding_torch_amd.Train -hp <yaml>` with
+    `Use_Multi_GPU: true` starts the ranks itself (one per entry of `Device`), as multi_gpu.sh does for the reference;
   * the training loss is accumulated ON DEVICE and read back only every `Logging_Interval` steps (the
     reference's per-step `.item()` is a host sync, Train.py:167).
 The step order is the reference's: forward -> loss -> zero_grad -> backward(+all-reduce) -> clip -> AdamW
@@ -30,7 +32,7 @@ from .Datasets import Collater, Dataset, DevicePrefetcher, Inference_Collater
 from .distributed import apply_gradient_allreduce, init_distributed, reduce_tensor
 from .Logger import Logger
 from .Modules import GE2E, GE2E_Loss, GE2E_Loss_Global
-from .Optim import FusedClipAdamW
+from .Optim import FusedClipAdamW, GradScaler
 
 logging.basicConfig(level=logging.INFO, stream=sys.stdout,
                     format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s")
@@ -106,6 +108,8 @@ class Trainer:
             max_norm=self.hp.Train.Gradient_Norm)
         self.scheduler = torch.optim.lr_scheduler.ExponentialLR(
             optimizer=self.optimizer, gamma=self.hp.Train.Learning_Rate.Decay, last_epoch=-1)
+        # Train.py:134: GradScaler(enabled=Use_Mixed_Precision).  Only float16 needs it (bfloat16 keeps fp32's exponent range)
+        self.scaler = GradScaler(enabled=self.model.precision == "fp16")
 
     # -------------------------------------------------------------------------------------- steps
     def Train_Step(self, features):
@@ -113,8 +117,10 @@ class Trainer:
         embeddings = self.model(features)
         loss = self.criterion(embeddings, self.hp.Train.Batch.Train.Pattern_per_Speaker)
         self.optimizer.zero_grad()
-        loss.backward()                      # HIP backward; gradient buckets all-reduced as they complete
-        self.optimizer.step()                # clip_grad_norm_(Gradient_Norm) + AdamW, fused (Train.py:154-162)
+        self.scaler.scale(loss).backward()   # HIP backward; gradient buckets all-reduced as they complete
+        self.scaler.unscale_(self.optimizer)
+        self.scaler.step(self.optimizer)     # unscale + inf check + clip_grad_norm_(Gradient_Norm) + AdamW, fused (Train.py:154-162)
+        self.scaler.update()
         self.steps += 1
         if self.tqdm is not None:
             self.tqdm.update(1)
@@ -258,14 +264,35 @@ class Trainer:
         logging.info("Finished training.")
 
 
+def launch_ranks(n, argv):
+    """`Use_Multi_GPU: true` without a launcher: start one rank per GPU (reference multi_gpu.sh:2 does it with
+    torch.distributed.launch) as a fresh child -- before this process makes any GPU call -- and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "speaker_embedding_torch_amd.Train", *argv]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main(argv=None):
     parser = argparse.ArgumentParser()
     parser.add_argument("-hp", "--hyper_parameters", required=True, type=str)
     parser.add_argument("-s", "--steps", default=0, type=int)
     parser.add_argument("-p", "--port", default=54321, type=int)          # accepted, unused (as in the reference)
     parser.add_argument("-r", "--local_rank", default=0, type=int)        # accepted, unused (as in the reference)
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = parser.parse_args(argv)
     hp = Load_Hyper_Parameters(args.hyper_parameters)
+    devices = [d for d in str(hp.Device).split(",") if d.strip() != ""] if hp.Device is not None else []
+    if hp.Use_Multi_GPU and "RANK" not in os.environ and len(devices) > 1:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", ",".join(devices))   # Train.py:356 sets CUDA_VISIBLE_DEVICES from hp.Device
+        sys.exit(launch_ranks(len(devices), argv))
     if int(os.getenv("WORLD_SIZE", "1")) == 1 and hp.Device is not None:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", str(hp.Device))      # Train.py:356 sets CUDA_VISIBLE_DEVICES
     if hp.Use_Multi_GPU:

@@ -4,6 +4,7 @@ import ctypes as C
 import os
 import threading
 
+from . import _build
 from ._build import LIB
 
 _lock = threading.Lock()
@@ -11,7 +12,9 @@ _lib = None
 
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
-PREC_F32, PREC_BF16 = 0, 1
+PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
+PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
+ABI_VERSION = 2
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD = 1, 2, 4, 8, 16, 32
 
 
@@ -25,6 +28,7 @@ class Config(C.Structure):
 _PF = C.POINTER(C.c_float)
 _SIG = {
     "ge2e_abi_version": (C.c_int, []),
+    "ge2e_source_hash": (C.c_char_p, []),
     "ge2e_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
     "ge2e_destroy": (C.c_int, [C.c_void_p]),
     "ge2e_last_error": (C.c_char_p, [C.c_void_p]),
@@ -56,6 +60,10 @@ _SIG = {
     "ge2e_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
+    "ge2e_clip_adamw_step_scaled": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
+                                              C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                              C.c_float, C.c_float, C.c_int]),
     "ge2e_mel_frames": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "ge2e_mel_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ge2e_mel_spectrogram": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -84,8 +92,13 @@ def load():
             for name, (res, args) in _SIG.items():
                 fn = getattr(lib, name)        # AttributeError if the ABI lost a symbol
                 fn.restype, fn.argtypes = res, args
-            if lib.ge2e_abi_version() != 1:
+            if lib.ge2e_abi_version() != ABI_VERSION:
                 raise RuntimeError("libge2e_hip.so ABI version mismatch")
+            built, want = lib.ge2e_source_hash().decode(), _build.source_hash()
+            if built != want:
+                raise RuntimeError(
+                    f"{LIB} is stale: it was compiled from sources with hash {built}, csrc/ now hashes to {want} "
+                    "(run `python -m speaker_embedding_torch_amd._build`)")
             _lib = lib
     return _lib
 
@@ -169,6 +182,12 @@ class Handle:
     def clip_adamw_step(self, stream, ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, norm, max_norm, lr, b1, b2, eps, wd, step):
         self.check(self.lib.ge2e_clip_adamw_step(self._h, stream, len(ptrs_p), ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel,
                                                  norm.data_ptr(), max_norm, lr, b1, b2, eps, wd, step), "ge2e_clip_adamw_step")
+
+    def clip_adamw_step_scaled(self, stream, ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, norm, max_norm, lr, b1, b2, eps, wd,
+                               scaler_state, growth, backoff, interval):
+        self.check(self.lib.ge2e_clip_adamw_step_scaled(self._h, stream, len(ptrs_p), ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel,
+                                                        norm.data_ptr(), max_norm, lr, b1, b2, eps, wd, scaler_state.data_ptr(),
+                                                        growth, backoff, interval), "ge2e_clip_adamw_step_scaled")
 
     def mel_frames(self, samples, n_fft, hop):
         return self.lib.ge2e_mel_frames(samples, n_fft, hop)

@@ -4,6 +4,7 @@
 #include "../../include/ge2e_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -43,9 +44,14 @@ struct ge2e_handle_s {
     std::vector<hipEvent_t> ev_pool;
     // backward overlap: weight-gradient GEMMs run on an internal side stream, fenced with events
     hipStream_t side = nullptr;
-    std::vector<hipEvent_t> fence_pool;    // hipEventDisableTiming events, reused every call
+    // One EventSet per in-flight backward.  A set is taken again only after its `done` event -- recorded on the
+    // caller's stream after the final join of that backward -- has completed, so no fence event is ever re-recorded
+    // while a stream may still have to wait on its previous record (a host thread can run several steps ahead).
+    struct EventSet { std::vector<hipEvent_t> ev; hipEvent_t done = nullptr; bool used = false; };
+    std::vector<EventSet*> event_sets;
     int overlap = 1;                       // GE2E_NO_OVERLAP=1 turns the side stream off
-    int num_cus = 0;                       // of the current device, queried at the first persistent launch
+    int num_cus = 0;                       // of the handle's device, queried at the first persistent launch
+    int device = -1;                       // device of the first GPU call; later calls on another current device are refused
 };
 
 namespace {
@@ -200,13 +206,15 @@ struct ProfScope {
 };
 
 // ------------------------------------------------------------------------------------------ launches
+// Dynamic LDS above 48 KB needs the function attribute raised first.  The largest size ever requested is remembered per call
+// site (a call site launches one kernel instantiation); a later, larger request (runtime-sized LDS) raises it again.
 #define GE2E_LAUNCH(h, kern, grid, block, smem, st, ...)                                                   \
     do {                                                                                                    \
-        static bool attr_done = false;                                                                      \
-        if (!attr_done && (size_t)(smem) > (size_t)48 * 1024) {  /* per call site: smem is a compile-time constant there */ \
+        static std::atomic<size_t> attr_max{(size_t)48 * 1024};                                             \
+        if ((size_t)(smem) > attr_max.load(std::memory_order_relaxed)) {                                    \
             hipError_t ea = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)); \
             if (ea != hipSuccess) return fail_hip(h, ea, "hipFuncSetAttribute " #kern);                     \
-            attr_done = true;                                                                               \
+            attr_max.store((size_t)(smem), std::memory_order_relaxed);                                      \
         }                                                                                                   \
         hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                       \
         hipError_t el = hipGetLastError();                                                                  \
@@ -296,8 +304,8 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
         if (!kl_off && a.K == 1024 && a.N == 256 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && a.ldr % 8 == 0) {
             const int ntiles = (a.M + 127) / 128;
             if (h->num_cus <= 0) {
-                int dev = 0, n = 0;
-                if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+                int dev = h->device >= 0 ? h->device : 0, n = 0;
+                if ((h->device < 0 && hipGetDevice(&dev) != hipSuccess) || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
                 h->num_cus = n;
             }
             const int grid = std::min(h->num_cus, ntiles);
@@ -389,8 +397,25 @@ int launch_attn_q0(ge2e_handle h, hipStream_t st, const AttnQ0Args& a, int n, bo
     return 0;
 }
 
+// A handle's side stream, fence events and CU count belong to ONE device: the one that is current at its first GPU call.
+// A later call with another device current would launch on a stream of the wrong device, so it is refused.
+int check_device(ge2e_handle h) {
+    int dev = -1;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail_hip(h, e, "hipGetDevice");
+    std::lock_guard<std::mutex> g(h->mu);
+    if (h->device < 0) h->device = dev;
+    else if (h->device != dev) {
+        h->err = "this handle was first used on device " + std::to_string(h->device) + " but the current device is " +
+                 std::to_string(dev) + " (make the tensors' device current around the call)";
+        return GE2E_EINVAL;
+    }
+    return 0;
+}
+
 int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_t ws_bytes, const Layout& L) {
     const ge2e_config& c = h->cfg;
+    { const int e = check_device(h); if (e) return e; }
     if (n <= 0 || t <= 0 || samples <= 0 || n % samples != 0) return fail(h, GE2E_EINVAL, "n_utts/frames/samples invalid");
     if (t > 32 * MAX_KT) return fail(h, GE2E_EUNSUPPORTED, "frames > 288 not supported by the attention kernels");
     if (t > c.max_position) return fail(h, GE2E_EINVAL, "frames > max_position");
@@ -407,21 +432,30 @@ int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_
 // latency-bound dgrad / attention / LayerNorm kernels of the main stream.
 struct SideCtx {
     ge2e_handle h; hipStream_t main_st; hipStream_t side = nullptr; bool on = false; size_t next = 0; int err = 0;
+    ge2e_handle_s::EventSet* set = nullptr;
     SideCtx(ge2e_handle h_, hipStream_t m) : h(h_), main_st(m) {
         if (!h->overlap) return;
         if (!h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return; }
+        // this backward's own event set: one whose previous backward has completed on the device, else a new one
+        std::lock_guard<std::mutex> g(h->mu);
+        for (auto* s : h->event_sets)
+            if (!s->used || (s->done && hipEventQuery(s->done) == hipSuccess)) { set = s; break; }
+        if (!set) {
+            set = new (std::nothrow) ge2e_handle_s::EventSet();
+            if (!set) return;
+            if (hipEventCreateWithFlags(&set->done, hipEventDisableTiming) != hipSuccess) { delete set; set = nullptr; return; }
+            h->event_sets.push_back(set);
+        }
+        set->used = true;
         side = h->side; on = true;
     }
     hipEvent_t ev() {
-        // reuse an event only once its previous record has completed (a host thread running several steps ahead
-        // of the GPU must not re-record an event another stream may still be about to wait on)
-        while (next < h->fence_pool.size() && hipEventQuery(h->fence_pool[next]) != hipSuccess) ++next;
-        if (next == h->fence_pool.size()) {
+        if (next == set->ev.size()) {
             hipEvent_t e = nullptr;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = 1; return nullptr; }
-            h->fence_pool.push_back(e);
+            set->ev.push_back(e);
         }
-        return h->fence_pool[next++];
+        return set->ev[next++];
     }
     hipStream_t wstream() const { return on ? side : main_st; }
     void fork() {                           // side waits for everything enqueued on main so far
@@ -438,6 +472,15 @@ struct SideCtx {
     void wait(hipEvent_t& e) {              // main waits for a side-stream reader before overwriting its input
         if (on && e && hipStreamWaitEvent(main_st, e, 0) != hipSuccess) err = 1;
         e = nullptr;
+    }
+    // End of a backward, on EVERY path (also an error return in the middle): the caller's stream waits for everything the
+    // side stream was given -- the caller may free the gradient buffer and the workspace right after the call -- and the
+    // set's `done` event marks the point after which its fence events may be recorded again.
+    void join() {
+        if (!on) return;
+        hipEvent_t e = mark();
+        wait(e);
+        if (hipEventRecord(set->done, main_st) != hipSuccess) err = 1;
     }
 };
 
@@ -574,7 +617,24 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
 }
 
 template <typename T>
+int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
+                  const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
+                  uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user);
+
+template <typename T>
 int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
+                  const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
+                  uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user) {
+    SideCtx sc(h, st);
+    const int rc = backward_body<T>(h, st, sc, mel, n, t, samples, P, d_emb, grads, ws, L, seed, step, cb, user);
+    sc.join();                                           // also when a launch failed half-way: nothing is left running on the side stream
+    if (rc) return rc;
+    if (sc.err) return fail(h, GE2E_EINVAL, "side-stream event fencing failed");
+    return 0;
+}
+
+template <typename T>
+int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
                   uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user) {
     const ge2e_config& c = h->cfg;
@@ -585,7 +645,6 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     };
     hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
     if (e != hipSuccess) return fail_hip(h, e, "zero grads");
-    SideCtx sc(h, st);
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     hipEvent_t g_set1 = nullptr, g_set2 = nullptr, g_dF = nullptr, g_dQKV = nullptr;   // last side-stream reader of a buffer
     {
@@ -607,7 +666,7 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
     const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
     const size_t esz = L.esz;
     for (int l = c.layers - 1; l >= 0; --l) {
-        if (stop_after >= 0 && c.layers - 1 - l >= stop_after) { hipEvent_t done = sc.mark(); sc.wait(done); return 0; }
+        if (stop_after >= 0 && c.layers - 1 - l >= stop_after) return 0;
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
         // the last layer runs on compact rows (one per utterance, frame 0) until its attention; see forward_impl
         const bool last = l == c.layers - 1;
@@ -758,11 +817,8 @@ int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t,
         w.R = R; w.N = d; w.K = c.mel_dim;
         CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
-        hipEvent_t done = sc.mark();
-        sc.wait(done);                                   // join: the caller's stream owns every gradient again
     }
-    if (sc.err) return fail(h, GE2E_EINVAL, "side-stream event fencing failed");
-    return 0;
+    return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again
 }
 
 struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, total; };
@@ -789,7 +845,11 @@ LossArgs loss_args(const float* emb, int S, int P, float w, float b, unsigned ch
 // ================================================================================================ C ABI
 extern "C" {
 
+#ifndef GE2E_SOURCE_HASH
+#define GE2E_SOURCE_HASH "unversioned"
+#endif
 int ge2e_abi_version(void) { return GE2E_ABI_VERSION; }
+const char* ge2e_source_hash(void) { return GE2E_SOURCE_HASH; }
 
 int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
     if (!cfg || !out) return GE2E_EINVAL;
@@ -810,7 +870,7 @@ int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
 
 int ge2e_destroy(ge2e_handle h) {
     if (!h) return 0;
-    for (hipEvent_t e : h->fence_pool) hipEventDestroy(e);
+    for (auto* s : h->event_sets) { for (hipEvent_t e : s->ev) hipEventDestroy(e); if (s->done) hipEventDestroy(s->done); delete s; }
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->side) hipStreamDestroy(h->side);
     delete h;
@@ -901,6 +961,7 @@ int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speaker
     if (speakers > 8192) return fail(h, GE2E_EUNSUPPORTED, "loss: more than 8192 speakers per batch");
     const LossLayout L = loss_layout(speakers, utts, h->cfg.emb);
     if (loss_ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "loss workspace too small");
+    CK(check_device(h));
     hipStream_t st = (hipStream_t)stream;
     LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
     a.loss = loss;
@@ -916,6 +977,7 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     if (!emb || !d_loss || !d_emb || !loss_ws || speakers <= 0 || utts <= 0) return fail(h, GE2E_EINVAL, "loss: bad argument");
     const LossLayout L = loss_layout(speakers, utts, h->cfg.emb);
     if (loss_ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "loss workspace too small");
+    CK(check_device(h));
     hipStream_t st = (hipStream_t)stream;
     LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
     a.gscale = d_loss; a.d_emb = d_emb;
@@ -926,22 +988,27 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     return 0;
 }
 
-int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
-                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
-                         float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
-                         float weight_decay, int64_t step) {
+static int clip_adamw_any(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                          float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                          float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, int64_t step, float* scaler, float growth, float backoff, int growth_interval) {
     if (!h) return GE2E_EINVAL;
-    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !norm_scratch || count <= 0 || step < 1)
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !norm_scratch || count <= 0 || (!scaler && step < 1))
         return fail(h, GE2E_EINVAL, "clip_adamw: bad argument");
+    if (scaler && (!(growth >= 1.0f) || !(backoff > 0.0f && backoff <= 1.0f) || growth_interval < 1))
+        return fail(h, GE2E_EINVAL, "clip_adamw: bad loss-scaling constants");
+    CK(check_device(h));
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < count; ++i)
         if (!params[i] || !grads[i] || !exp_avg[i] || !exp_avg_sq[i] || numel[i] <= 0 || numel[i] > 2147483647LL)
             return fail(h, GE2E_EINVAL, "clip_adamw: null tensor or bad numel");
-    if (max_norm > 0.0f) {
+    const bool need_norm = max_norm > 0.0f || scaler != nullptr;      // the norm doubles as the inf / nan detector
+    if (need_norm) {
         hipError_t e = hipMemsetAsync(norm_scratch, 0, 4, st);
         if (e != hipSuccess) return fail_hip(h, e, "zero norm");
     }
-    for (int pass = (max_norm > 0.0f ? 0 : 1); pass < 2; ++pass)          // pass 0: squared norm, pass 1: update
+    OptArgs last{};
+    for (int pass = (need_norm ? 0 : 1); pass < 2; ++pass)          // pass 0: squared norm, pass 1: update
         for (int b = 0; b < count; b += OPT_MAX_TENSORS) {
             OptArgs a{};
             const int cnt = std::min(OPT_MAX_TENSORS, count - b);
@@ -953,12 +1020,35 @@ int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* p
             }
             a.chunk0[cnt] = chunks; a.ntensors = cnt; a.sumsq = norm_scratch; a.max_norm = max_norm;
             a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-            a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
-            a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+            a.scaler = scaler; a.growth = growth; a.backoff = backoff; a.growth_interval = growth_interval;
+            if (!scaler) {
+                a.bc1 = (float)(1.0 - std::pow((double)beta1, (double)step));
+                a.bc2_sqrt = (float)std::sqrt(1.0 - std::pow((double)beta2, (double)step));
+            }
             if (pass == 0) GE2E_LAUNCH(h, opt_norm_kernel, dim3(chunks), dim3(256), 0, st, a);
             else GE2E_LAUNCH(h, opt_adamw_kernel, dim3(chunks), dim3(256), 0, st, a);
+            last = a;
         }
+    if (scaler) GE2E_LAUNCH(h, opt_scaler_update_kernel, dim3(1), dim3(64), 0, st, last);
     return 0;
+}
+
+int ge2e_clip_adamw_step(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                         float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                         float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, int64_t step) {
+    return clip_adamw_any(h, stream, count, params, grads, exp_avg, exp_avg_sq, numel, norm_scratch, max_norm, lr, beta1, beta2,
+                          eps, weight_decay, step, nullptr, 1.0f, 1.0f, 1);
+}
+
+int ge2e_clip_adamw_step_scaled(ge2e_handle h, void* stream, int count, float* const* params, float* const* grads,
+                                float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                                float* norm_scratch, float max_norm, float lr, float beta1, float beta2, float eps,
+                                float weight_decay, float* scaler_state, float growth_factor, float backoff_factor,
+                                int growth_interval) {
+    if (h && !scaler_state) return fail(h, GE2E_EINVAL, "clip_adamw: null scaler state");
+    return clip_adamw_any(h, stream, count, params, grads, exp_avg, exp_avg_sq, numel, norm_scratch, max_norm, lr, beta1, beta2,
+                          eps, weight_decay, 0, scaler_state, growth_factor, backoff_factor, growth_interval);
 }
 
 void* ge2e_bucket_stream(ge2e_handle h, void* stream) {
@@ -999,6 +1089,7 @@ int ge2e_mel_spectrogram(ge2e_handle h, void* stream, const float* wav, int batc
     MelLayout m;
     if (!mel_layout(batch, samples, n_fft, hop, n_mels, m)) return fail(h, GE2E_EUNSUPPORTED, "mel front-end: unsupported n_fft / hop / n_mels / length");
     if (workspace_bytes < m.total) return fail(h, GE2E_EINVAL, "mel front-end: workspace too small");
+    CK(check_device(h));
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     const int pad = (n_fft - hop) / 2;

@@ -369,6 +369,11 @@ struct OptArgs {
     float* sumsq;                        // device scalar, zeroed before the norm kernel
     float max_norm;                      // <= 0: no clipping
     float lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt;
+    // mixed-precision loss scaling (null: off).  scaler = { scale, growth_tracker, found_inf, steps_taken } on the device:
+    // gradients hold scale x the true gradient; a non-finite squared norm skips the whole update (GradScaler.step) and
+    // the bias corrections come from the device-side step count, so a skipped step needs no host round trip
+    float* scaler;
+    float growth, backoff; int growth_interval;
 };
 constexpr int OPT_CHUNK = 4096;
 
@@ -395,10 +400,18 @@ __global__ void __launch_bounds__(256) opt_norm_kernel(const OptArgs a) {
 __global__ void __launch_bounds__(256) opt_adamw_kernel(const OptArgs a) {
     const int t = opt_find(a, blockIdx.x);
     const int base = (blockIdx.x - a.chunk0[t]) * OPT_CHUNK;
-    float coef = 1.0f;
-    if (a.max_norm > 0.0f) coef = fminf(1.0f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));
+    float coef = 1.0f, bc1 = a.bc1, bc2_sqrt = a.bc2_sqrt;
+    if (a.scaler) {
+        const float ss = *a.sumsq;
+        if (!(fabsf(ss) <= 3.0e38f)) return;                 // inf / nan somewhere: GradScaler.step skips the optimizer step
+        const float inv = 1.0f / a.scaler[0], tt = a.scaler[3] + 1.0f;
+        bc1 = 1.0f - powf(a.beta1, tt);
+        bc2_sqrt = sqrtf(1.0f - powf(a.beta2, tt));
+        coef = inv;                                          // GradScaler.unscale_
+        if (a.max_norm > 0.0f) coef *= fminf(1.0f, a.max_norm / (sqrtf(ss) * inv + 1e-6f));
+    } else if (a.max_norm > 0.0f) coef = fminf(1.0f, a.max_norm / (sqrtf(*a.sumsq) + 1e-6f));
     float* __restrict__ p = a.p[t]; float* __restrict__ g = a.g[t]; float* __restrict__ m = a.m[t]; float* __restrict__ v = a.v[t];
-    const float decay = 1.0f - a.lr * a.weight_decay, step_size = a.lr / a.bc1;
+    const float decay = 1.0f - a.lr * a.weight_decay, step_size = a.lr / bc1;
     for (int q = threadIdx.x; q < OPT_CHUNK; q += 256) {
         const int e = base + q;
         if (e >= a.numel[t]) break;
@@ -406,8 +419,24 @@ __global__ void __launch_bounds__(256) opt_adamw_kernel(const OptArgs a) {
         const float mm = a.beta1 * m[e] + (1.0f - a.beta1) * gr;
         const float vv = a.beta2 * v[e] + (1.0f - a.beta2) * gr * gr;
         g[e] = gr; m[e] = mm; v[e] = vv;
-        p[e] = p[e] * decay - step_size * (mm / (sqrtf(vv) / a.bc2_sqrt + a.eps));
+        p[e] = p[e] * decay - step_size * (mm / (sqrtf(vv) / bc2_sqrt + a.eps));
     }
+}
+
+// GradScaler.update after the step kernel has read the state: one thread
+__global__ void opt_scaler_update_kernel(const OptArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float ss = *a.sumsq;
+    const bool finite = fabsf(ss) <= 3.0e38f;
+    float scale = a.scaler[0], tracker = a.scaler[1];
+    if (finite) {
+        a.scaler[3] += 1.0f;
+        tracker += 1.0f;
+        if (tracker >= (float)a.growth_interval) { scale *= a.growth; tracker = 0.0f; }
+    } else {
+        scale *= a.backoff; tracker = 0.0f;
+    }
+    a.scaler[0] = scale; a.scaler[1] = tracker; a.scaler[2] = finite ? 0.0f : 1.0f;
 }
 
 }  // namespace ge2e

@@ -21,7 +21,7 @@ from . import _lib
 MAX_WAV_VALUE = 32768.0
 _basis_cache = {}
 _lock = threading.Lock()
-_handle = None
+_handle = {}
 
 
 def load_wav(full_path):
@@ -55,12 +55,12 @@ def slaney_mel_basis(sampling_rate, n_fft, num_mels, fmin=0.0, fmax=None):
     return basis.astype(np.float32)
 
 
-def _get_handle():
-    global _handle
+def _get_handle(device_index):
     with _lock:
-        if _handle is None:
-            _handle = _lib.Handle(emb=256, heads=4)
-        return _handle
+        h = _handle.get(device_index)
+        if h is None:             # one handle per device (a handle belongs to the device of its first call)
+            h = _handle[device_index] = _lib.Handle(emb=256, heads=4)
+        return h
 
 
 def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin, fmax, center=False):
@@ -78,7 +78,7 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
         basis = torch.from_numpy(slaney_mel_basis(sampling_rate, n_fft, num_mels, fmin, fmax)).to(y.device)
         with _lock:
             _basis_cache[key] = basis
-    hnd = _get_handle()
+    hnd = _get_handle(y.device.index)
     batch, samples = y.shape
     frames = hnd.mel_frames(samples, n_fft, hop_size)
     nbytes = hnd.mel_workspace_bytes(batch, samples, n_fft, hop_size, num_mels)
@@ -86,5 +86,6 @@ def mel_spectrogram(y, n_fft, num_mels, sampling_rate, hop_size, win_size, fmin,
         raise RuntimeError(f"mel_spectrogram: unsupported geometry (samples={samples}, n_fft={n_fft}, hop={hop_size}, mels={num_mels})")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=y.device)
     out = torch.empty(batch, num_mels, frames, dtype=torch.float32, device=y.device)
-    hnd.mel_spectrogram(torch.cuda.current_stream(y.device).cuda_stream, y, n_fft, hop_size, num_mels, basis, out, ws)
+    with torch.cuda.device(y.device):
+        hnd.mel_spectrogram(torch.cuda.current_stream(y.device).cuda_stream, y, n_fft, hop_size, num_mels, basis, out, ws)
     return out

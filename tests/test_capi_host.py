@@ -39,7 +39,7 @@ def test_header_symbols_all_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ge2e_abi_version() == 1
+    assert lib.ge2e_abi_version() == _lib.ABI_VERSION
 
 
 def test_param_table_is_reference_state_dict_order():
@@ -136,3 +136,35 @@ def test_product_code_never_imports_oracle():
         for f in files:
             if f.endswith((".py", ".hip", ".cuh", ".h")):
                 assert not pat.search(open(os.path.join(root, f)).read()), f
+
+
+def test_build_tracks_every_source_and_loader_refuses_a_stale_binary(monkeypatch):
+    """the dependency list is csrc/*.hip + csrc/*.cuh + the header (no hand-kept list), and a binary whose
+    embedded source hash differs from the csrc/ beside it must not load."""
+    import glob
+    from speaker_embedding_torch_amd import _build
+    deps = set(_build.dependencies())
+    csrc = os.path.join(REPO, "speaker_embedding_torch_amd", "csrc")
+    assert set(glob.glob(os.path.join(csrc, "*.cuh")) + glob.glob(os.path.join(csrc, "*.hip"))) <= deps
+    assert os.path.join(REPO, "include", "ge2e_hip.h") in deps
+    lib = _lib.load()
+    assert lib.ge2e_source_hash().decode() == _build.source_hash() == _build.built_hash()
+    assert not _build.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_build, "source_hash", lambda: "0" * 32)
+    assert _build.needs_build()
+    with pytest.raises(RuntimeError, match="stale"):
+        _lib.load()
+
+
+def test_precision_a_hyper_parameter_file_asks_for():
+    """Use_Mixed_Precision means float16 + GradScaler in the reference (Train.py:134,145); bf16 is this build's optional key."""
+    from argparse import Namespace
+    from speaker_embedding_torch_amd.Modules import default_precision
+    assert default_precision(Namespace(Use_Mixed_Precision=False)) == "fp32"
+    assert default_precision(Namespace(Use_Mixed_Precision=True)) == "fp16"
+    assert default_precision(Namespace(Use_Mixed_Precision=True, Mixed_Precision_Dtype="bf16")) == "bf16"
+    assert default_precision(Namespace(Use_Mixed_Precision=False, Mixed_Precision_Dtype="bf16")) == "fp32"
+    from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
+    hp = Load_Hyper_Parameters(os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
+    assert default_precision(hp) == "bf16"          # the shipped recipe = BASELINE.json configs[1]

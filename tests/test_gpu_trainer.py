@@ -272,3 +272,65 @@ def test_training_learns_synthetic_speakers(tmp_path, bf16):
     cent = torch.nn.functional.normalize(e.mean(1), dim=1)
     sim = torch.einsum("spd,cd->spc", e, cent)                                   # [S, P, S]
     assert (sim.argmax(-1) == torch.arange(S)[:, None]).float().mean() > 0.9
+
+
+def test_loss_scaled_step_matches_torch_gradscaler_semantics():
+    """ge2e_clip_adamw_step_scaled == GradScaler.unscale_ + clip_grad_norm_ + AdamW + GradScaler.update (reference
+    Train.py:153-162) with the state on the device: clean steps match the unscaled optimizer fed the true gradients,
+    an inf / nan gradient skips the step (parameters, moments, step count untouched) and halves the scale, and
+    `growth_interval` clean steps in a row double it."""
+    from speaker_embedding_torch_amd.Optim import FusedClipAdamW, GradScaler
+    torch.manual_seed(1)
+    shapes = [(256, 80, 1), (1,), (768, 256), (4099,)]
+    pa = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-6)
+    oa, ob = FusedClipAdamW(pa, max_norm=1.0, **kw), FusedClipAdamW(pb, max_norm=1.0, **kw)
+    sc = GradScaler(init_scale=1024.0, growth_interval=3)
+    scale, tracker, taken = 1024.0, 0, 0
+    for step in range(9):
+        bad = step in (2, 6)
+        gs = [torch.randn_like(p) * (0.5 if step % 2 == 0 else 1e-3) for p in pa]
+        before = [p.detach().clone() for p in pa]
+        for p, q, g in zip(pa, pb, gs):
+            p.grad, q.grad = g * scale, g.clone()
+        if bad:
+            pa[2].grad[5, 7] = float("inf") if step == 2 else float("nan")
+        sc.step(oa)
+        sc.update()
+        if bad:
+            for p, b in zip(pa, before):
+                assert torch.equal(p, b)                                    # skipped: nothing moved
+            scale, tracker = scale * 0.5, 0
+        else:
+            ob.step()
+            taken += 1
+            tracker += 1
+            if tracker == 3:
+                scale, tracker = scale * 2.0, 0
+            for p, q in zip(pa, pb):
+                assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), step
+                assert torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-7)   # left unscaled and clipped in place
+        assert sc.get_scale() == scale and sc.steps_taken() == taken, (step, sc.get_scale(), scale)
+        assert float(sc.state(pa[0].device)[2]) == (1.0 if bad else 0.0)
+    sd = oa.state_dict()
+    assert all(float(st["step"]) == float(taken) for st in sd["state"].values())    # skipped steps do not count
+    assert set(sc.state_dict()) == {"scale", "growth_factor", "backoff_factor", "growth_interval", "_growth_tracker"}
+    assert GradScaler(enabled=False).scale(torch.ones((), device="cuda")).item() == 1.0
+
+
+@pytest.mark.timeout(300)
+def test_many_steps_enqueued_without_a_host_sync(tmp_path):
+    """Regression for the round-1 stream deadlock (a fence event re-recorded while the side stream still had to wait on
+    its previous record): the host runs many Train_Steps ahead of the GPU, never synchronising, and everything must
+    drain.  Each in-flight backward now owns its event set, recycled only after that backward completed on the device."""
+    from speaker_embedding_torch_amd.Train import Trainer
+    hp_path = write_hp(tmp_path, bf16=True, **{"Train.Batch.Train.Speaker": 16, "Train.Batch.Train.Pattern_per_Speaker": 8})
+    tr = Trainer(hp_path, datasets={})
+    xs = [torch.randn(128, 80, 96, device="cuda") for _ in range(2)]
+    losses = [tr.Train_Step(xs[i & 1]) for i in range(60)]      # no .item(), no synchronize inside the loop
+    torch.cuda.synchronize()
+    vals = torch.stack([l.detach() for l in losses]).cpu()
+    assert torch.isfinite(vals).all()
+    hnd = tr.model._handle()
+    assert hnd is not None and tr.steps == 60

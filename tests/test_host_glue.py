@@ -139,3 +139,46 @@ def test_hyper_parameters_yaml_has_reference_schema():
     assert hp.Train.Inference.Samples == 5 and hp.Train.ADAM.Epsilon == 1e-6
     for key in ("Checkpoint_Path", "Log_Path", "Use_Mixed_Precision", "Use_Multi_GPU", "Device"):
         assert hasattr(hp, key)
+
+
+def test_bench_starts_its_own_ranks_for_gpus_gt_1():
+    """`python bench.py --gpus N` (no launcher, as the driver calls it) must start N ranks itself.
+    --dry-launch rendezvous them over gloo on the CPU and prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                   # exactly ONE line on stdout
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["ok"] and out["n_gpus"] == 2 and out["config"]["parallelism"] == "dp2"
+    err = r.stderr.decode()
+    assert "dry-launch rank 0 / world 2" in err and "dry-launch rank 1 / world 2" in err
+
+
+def test_trainer_launcher_command_line():
+    """`Use_Multi_GPU: true` + a Device list makes Train.main start one rank per GPU through torch.distributed.run
+    (the reference does it with multi_gpu.sh:2); here only the command it would run is checked."""
+    import subprocess
+    from speaker_embedding_torch_amd import Train
+    seen = {}
+
+    def fake_run(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+
+        class R:
+            returncode = 0
+        return R()
+    orig = subprocess.run
+    subprocess.run = fake_run
+    try:
+        assert Train.launch_ranks(4, ["-hp", "x.yaml"]) == 0
+    finally:
+        subprocess.run = orig
+    cmd = seen["cmd"]
+    assert "--nproc-per-node=4" in cmd and "torch.distributed.run" in cmd and cmd[-2:] == ["-hp", "x.yaml"]
+    assert "127.0.0.1" in cmd and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert os.access(os.path.join(REPO, "multi_gpu.sh"), os.X_OK)

@@ -168,3 +168,32 @@ def test_backward_matches_finite_difference_fp64():
             p[idx] = old
             fd = (lp - lm) / (2 * h)
             assert abs(fd - grads[name][idx]) < 1e-6 + 1e-4 * abs(fd), (name, idx, fd, grads[name][idx])
+
+
+def test_torch_cpu_restatement_is_the_reference_computation(cfg1, golden):
+    """bench.py's cpu_baseline times oracle/torch_restatement.py; pin it to the reference's goldens (eval d-vectors, loss)
+    and to the numpy oracle's gradients, so the baseline number belongs to the right computation."""
+    import torch
+    from oracle import torch_restatement as TR
+    params, x = cfg1
+    m = TR.EncoderCPU(p_pe=0.0, p_tf=0.0)
+    m.load_named(params)
+    m.eval()
+    with torch.no_grad():
+        emb = m(torch.from_numpy(x))
+        loss = TR.ge2e_loss_cpu(emb, P)
+    assert np.abs(emb.numpy() - golden["G1_emb"]).max() < 2e-6
+    assert abs(float(loss) - float(golden["G2_loss"][0])) < 2e-6
+    m.train()                                    # dropout rates are 0: train mode differs only by being differentiable
+    TR.ge2e_loss_cpu(m(torch.from_numpy(x)), P).backward()
+    e_np, c = O.encoder_forward(params, x, train=False)
+    _, lc = O.loss_forward(e_np, P)
+    g_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    named = dict(m.named_parameters())
+    for ours, theirs in (("transformer.layers.1.linear1.weight", "transformer.layers.1.linear1.weight"),
+                         ("transformer.layers.0.self_attn.in_proj_weight", "transformer.layers.0.self_attn.in_proj_weight"),
+                         ("alpha", "positional_encoding.alpha")):
+        assert rel_l2(named[ours].grad.numpy().reshape(-1), g_ref[theirs].reshape(-1)) < 2e-4, ours
+    assert rel_l2(named["prenet.weight"].grad.numpy(), g_ref["prenet.weight"][:, :, 0]) < 2e-4
+    ms = m(torch.from_numpy(O.formula_mel(3, 4 * 5, 80, 64)), samples=5)          # slice mean before the projection
+    assert ms.shape == (4, 256)
