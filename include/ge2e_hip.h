@@ -178,7 +178,8 @@ int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_
 
 /* Diagnostics: byte offset/size inside the workspace of a named intermediate of the last forward
  * ("h0", "qkv.<l>", "o.<l>", "h1.<l>", "f.<l>", "h2.<l>", and after a backward the scratch of the LAST
- * processed layer: "dF", "dHb", "dP", "dM", "dO", "dQKV", "dHa"; element type follows cfg.precision).
+ * processed FULL layer: "dF", "dHb", "dP1", "dM1" (norm2 backward), "dP", "dM" (norm1 backward), "dO", "dQKV", "dHa";
+ * element type follows cfg.precision -- except "rstd1.<l>", "rstd2.<l>" and "lse.<l>", which are fp32; "xt" = the packed mel rows).
  * The LAST layer is evaluated for frame 0 only (nothing else of it is consumed, Modules.py:54), so its
  * "o", "h1", "f", "h2" taps are compact [n_utts, width] and its "qkv" holds q in frame-0 rows only.
  * Used by the parity tests to localise a failing kernel; returns GE2E_EINVAL for unknown names. */

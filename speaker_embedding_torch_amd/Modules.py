@@ -252,11 +252,12 @@ class GE2E(torch.nn.Module):
             ws.fill_(0xFF)
         return ws
 
-    def workspace_view(self, name, n, t, train=True):
-        """Diagnostics for the parity tests: a typed view of a named intermediate of the last forward."""
+    def workspace_view(self, name, n, t, train=True, dtype=None):
+        """Diagnostics for the parity tests: a typed view of a named intermediate of the last forward
+        (`dtype=torch.float32` for the fp32 side tables "rstd1.<l>", "rstd2.<l>", "lse.<l>")."""
         off, size = self._handle().debug_tap(name, n, t, train)
         ws = self._ws[(bool(train), self.precision)]
-        dt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[self.precision]
+        dt = dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[self.precision]
         return ws[off:off + size].view(dt)
 
     # -- reference API -------------------------------------------------------------------------

@@ -23,11 +23,13 @@ struct AttnArgs {
 template <typename T> __device__ __forceinline__ float exp_prec(float x);
 template <> __device__ __forceinline__ float exp_prec<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ float exp_prec<bf16_t>(float x) { return __expf(x); }
+template <> __device__ __forceinline__ float exp_prec<f16_t>(float x) { return __expf(x); }
 // exp(score * scale - offset) with the constants folded for v_exp_f32 (= 2^x) in bf16 mode: callers pass
 // scale * EXPK and offset * EXPK and call exp_k (one fma + one exp per probability); fp32 mode keeps expf.
 template <typename T> struct ExpK;
 template <> struct ExpK<float> { static constexpr float K = 1.0f; static __device__ __forceinline__ float ex(float x) { return expf(x); } };
 template <> struct ExpK<bf16_t> { static constexpr float K = 1.4426950408889634f; static __device__ __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x); } };
+template <> struct ExpK<f16_t> : ExpK<bf16_t> {};
 
 namespace attn {
 template <typename T> struct Geo {

@@ -1,11 +1,13 @@
 // Shared device helpers for the GE2E hot-path kernels (gfx950 / CDNA4 only).
 //
-// Two arithmetic modes share every kernel template:
+// Three arithmetic modes share every kernel template:
 //   T = float  : v_mfma_f32_16x16x4_f32   (exact fp32 fma chain; the <=1e-4 parity path)
 //   T = bf16_t : v_mfma_f32_16x16x32_bf16 (bf16 storage, fp32 accumulate; the throughput path)
-// An MFMA operand "fragment" is always 16 bytes per lane (4 f32 / 8 bf16); one "k-group" is the
-// 64 bytes of K that the four 16-lane groups of a wave cover together (16 f32 / 32 bf16 values).
-// So LDS tiles have the same BYTE layout in both modes and only `mma16` differs.
+//   T = f16_t  : v_mfma_f32_16x16x32_f16  (IEEE half storage, fp32 accumulate: the reference's own autocast dtype,
+//                Train.py:145; 3 more mantissa bits than bf16, 5 exponent bits -> gradients need loss scaling)
+// An MFMA operand "fragment" is always 16 bytes per lane (4 f32 / 8 x 16-bit); one "k-group" is the
+// 64 bytes of K that the four 16-lane groups of a wave cover together (16 f32 / 32 16-bit values).
+// So LDS tiles have the same BYTE layout in all modes and only `mma16` and the conversions differ.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -13,6 +15,8 @@
 namespace ge2e {
 
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -25,6 +29,10 @@ template <> struct Prec<float> {
     static constexpr int KG = 16;    // k values per k-group
 };
 template <> struct Prec<bf16_t> {
+    static constexpr int FRAG = 8;
+    static constexpr int KG = 32;
+};
+template <> struct Prec<f16_t> {
     static constexpr int FRAG = 8;
     static constexpr int KG = 32;
 };
@@ -48,18 +56,31 @@ template <> __device__ __forceinline__ f32x4 mma16<bf16_t>(u32x4 a, u32x4 b, f32
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+template <> __device__ __forceinline__ f32x4 mma16<f16_t>(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------
 // scalar conversions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+__device__ __forceinline__ float to_f32(f16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }     // round to nearest even; overflow -> inf (the loss scaler's cue)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
     unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
+    return (unsigned)a | ((unsigned)b << 16);
+}
+
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    unsigned short a = __builtin_bit_cast(unsigned short, (f16_t)lo);
+    unsigned short b = __builtin_bit_cast(unsigned short, (f16_t)hi);
     return (unsigned)a | ((unsigned)b << 16);
 }
 
@@ -79,6 +100,13 @@ template <> __device__ __forceinline__ u32x4 pack_acc<bf16_t>(f32x4 t0, f32x4 t1
     return r;
 }
 
+template <> __device__ __forceinline__ u32x4 pack_acc<f16_t>(f32x4 t0, f32x4 t1) {
+    u32x4 r;
+    r.x = pack_f16x2(t0[0], t0[1]); r.y = pack_f16x2(t0[2], t0[3]);
+    r.z = pack_f16x2(t1[0], t1[1]); r.w = pack_f16x2(t1[2], t1[3]);
+    return r;
+}
+
 // 4 consecutive output elements of type T from 4 floats (8 B for bf16, 16 B for f32)
 __device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
     *(f32x4*)p = f32x4{a, b, c, d};
@@ -87,7 +115,16 @@ __device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, flo
     u32x2 v; v.x = pack_bf16x2(a, b); v.y = pack_bf16x2(c, d);
     *(u32x2*)p = v;
 }
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+    u32x2 v; v.x = pack_f16x2(a, b); v.y = pack_f16x2(c, d);
+    *(u32x2*)p = v;
+}
 __device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+__device__ __forceinline__ f32x4 load4(const f16_t* p) {
+    typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+    const f16x4_t v = *(const f16x4_t*)p;
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
 __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
     u32x2 v = *(const u32x2*)p;
     f32x4 r;
@@ -122,7 +159,7 @@ template <> __device__ __forceinline__ u32x4 frag_tr<float>(const unsigned char*
     r.w = *(const unsigned*)(p + 3 * ld);
     return r;
 }
-template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char* tile, int ld, int r0, int c0, int lane) {
+__device__ __forceinline__ u32x4 frag_tr16(const unsigned char* tile, int ld, int r0, int c0, int lane) {
     // ds_read_b64_tr_b16: within a 16-lane group, lane 4q+p supplies the address of (row q, cols 4p..4p+3)
     // of a 4x16 block and receives column (4q+p) of the 4 rows.  EXEC must be all ones.
     const int i = lane & 15, g = lane >> 4;
@@ -133,6 +170,8 @@ template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char
     u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
     return u32x4{l2.x, l2.y, h2.x, h2.y};
 }
+template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char* tile, int ld, int r0, int c0, int lane) { return frag_tr16(tile, ld, r0, c0, lane); }
+template <> __device__ __forceinline__ u32x4 frag_tr<f16_t>(const unsigned char* tile, int ld, int r0, int c0, int lane) { return frag_tr16(tile, ld, r0, c0, lane); }
 
 // ---------------------------------------------------------------------------------------------
 // counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep.  One 32-bit hash serves the

@@ -114,7 +114,7 @@ struct Layout {
 Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_max = 1) {
     (void)samples_max;
     Layout L;
-    L.esz = c.precision == GE2E_PREC_BF16 ? 2 : 4;
+    L.esz = c.precision == GE2E_PREC_F32 ? 4 : 2;
     L.KP = 128;                  // mel_dim <= 128, padded to one 128-column operand tile
     L.R = n * t;
     size_t off = 0;
@@ -252,7 +252,7 @@ inline bool ws_shape(const GemmArgs& a) {
     static const bool off = getenv("GE2E_NO_WS_GEMM") != nullptr;
     return !off && a.K == 256 && a.N % 256 == 0 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0;
 }
-template <int EPI>
+template <typename T, int EPI>
 int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK);
     if (EPI == EPI_LN && a.N != 256) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: the LayerNorm epilogue needs N == 256");
@@ -263,7 +263,7 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if (parts < 8) parts = 8;
     const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0));
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
-    auto kern = gemm_ws_kernel<EPI, 256>;
+    auto kern = gemm_ws_kernel<T, EPI, 256>;
     GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_smem<EPI, 256>()), st, a, parts, ntiles);
     return 0;
 }
@@ -271,7 +271,7 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 // LayerNorm backward + the K = 256 GEMM that consumes it, one launch (gemm_ws_lnbwd_kernel).  a.A = dy, a.gamma / beta /
 // rstd / drop / drow_mul describe the LayerNorm and the dropout in front of the sub-layer, f the rest.
 inline bool lnfuse_on() { static const bool off = getenv("GE2E_NO_LNFUSE") != nullptr; return !off; }
-template <int EPI>
+template <typename T, int EPI>
 int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const LnFuseArgs& f) {
     const int cg = a.N / 256, ntiles = (a.M + 15) / 16;
     int parts = (512 / cg) / 8 * 8;
@@ -279,7 +279,7 @@ int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const
     if (parts < 8) parts = 8;
     const double abytes = 2.0 * ((double)a.M * 256 * (f.dmask ? 4.0 : 3.0) + (double)a.N * a.K + (double)a.M * a.N * (EPI == EPI_MASK ? 2.0 : 1.0));
     ProfScope ps(h, st, GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
-    auto kern = gemm_ws_lnbwd_kernel<EPI>;
+    auto kern = gemm_ws_lnbwd_kernel<T, EPI>;
     GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_lnbwd_smem<EPI>()), st, a, f, parts, ntiles);
     return 0;
 }
@@ -287,7 +287,7 @@ int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const
 template <typename T, int EPI, int ALOAD = ALOAD_ROW>
 int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI>() && ALOAD == ALOAD_ROW) {
-        if (ws_shape(a)) return launch_gemm_ws<EPI>(h, st, a);
+        if (ws_shape(a)) return launch_gemm_ws<T, EPI>(h, st, a);
     }
     // the VALU-heavy ReLU + dropout epilogue gains from a third resident block (single LDS stage: 35 KB), measured
     // 179 -> 144 us for FFN1; the other epilogues measure the same either way and keep the one-barrier double buffer
@@ -297,7 +297,7 @@ int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 template <typename T>
 int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI_LN>()) {
-        if (ws_shape(a)) return launch_gemm_ws<EPI_LN>(h, st, a);
+        if (ws_shape(a)) return launch_gemm_ws<T, EPI_LN>(h, st, a);
         // FFN2 + LayerNorm (K = 1024): persistent stage-stream kernel, one 512-thread block per CU (gemm_kl.cuh).  It needs a
         // whole CU's LDS, so it is used where nothing shares the machine (the forward chain), not beside the weight gradients.
         static const bool kl_off = getenv("GE2E_NO_KL_GEMM") != nullptr;
@@ -311,7 +311,7 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
             const int grid = std::min(h->num_cus, ntiles);
             const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + 2.0 * (double)a.M * a.N);
             ProfScope ps(h, st, GE2E_K_GEMM_LN, 2.0 * a.M * a.N * (double)a.K, abytes);
-            auto kern = gemm_kl_kernel<EPI_LN, 1024>;
+            auto kern = gemm_kl_kernel<T, EPI_LN, 1024>;
             GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), (gemm_kl_smem<EPI_LN>()), st, a, ntiles);
             return 0;
         }
@@ -735,7 +735,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             f.dgamma = G(lp(l, L_N1_W)); f.dbeta = G(lp(l, L_N1_B));
             ado.A = b_dHb; ado.gamma = P[lp(l, L_N1_W)]; ado.beta = P[lp(l, L_N1_B)];
             ado.rstd = (float*)(ws + L.rstd1[l]); ado.drop = d_sa; ado.drow_mul = rmul;
-            CK((launch_gemm_ws_lnbwd<EPI_NONE>(h, st, ado, f)));
+            if constexpr (sizeof(T) == 2) CK((launch_gemm_ws_lnbwd<T, EPI_NONE>(h, st, ado, f)));
         } else {
         {   // norm1 backward
             LnBwdArgs a{};
@@ -857,7 +857,7 @@ int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
     if (cfg->emb != 256 || cfg->heads <= 0 || cfg->emb / cfg->heads != 64 || cfg->emb % cfg->heads != 0) return GE2E_EUNSUPPORTED;
     if (cfg->layers < 1 || cfg->layers > MAX_LAYERS || cfg->mel_dim < 1 || cfg->mel_dim > 128) return GE2E_EUNSUPPORTED;
     if (cfg->ffn % 128 != 0 || cfg->ffn < 128 || cfg->max_position < 1) return GE2E_EUNSUPPORTED;
-    if (cfg->precision != GE2E_PREC_F32 && cfg->precision != GE2E_PREC_BF16) return GE2E_EINVAL;
+    if (cfg->precision != GE2E_PREC_F32 && cfg->precision != GE2E_PREC_BF16 && cfg->precision != GE2E_PREC_F16) return GE2E_EINVAL;
     if (cfg->pe_dropout < 0.f || cfg->pe_dropout >= 1.f || cfg->tf_dropout < 0.f || cfg->tf_dropout >= 1.f) return GE2E_EINVAL;
     ge2e_handle h = new (std::nothrow) ge2e_handle_s();
     if (!h) return GE2E_EINVAL;
@@ -910,6 +910,8 @@ static int encoder_forward_any(ge2e_handle h, void* stream, const void* mel, boo
     unsigned char* ws = (unsigned char*)workspace;
     if (h->cfg.precision == GE2E_PREC_BF16)
         return forward_impl<bf16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+    if (h->cfg.precision == GE2E_PREC_F16)
+        return forward_impl<f16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
     return forward_impl<float>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
 }
 
@@ -946,6 +948,8 @@ int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int 
     unsigned char* ws = (unsigned char*)workspace;
     if (h->cfg.precision == GE2E_PREC_BF16)
         return backward_impl<bf16_t>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
+    if (h->cfg.precision == GE2E_PREC_F16)
+        return backward_impl<f16_t>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
     return backward_impl<float>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
 }
 
@@ -1162,6 +1166,12 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
     else if (base == "h1") { *offset_bytes = L.h1[l]; *size_bytes = Rl * d * e; }
     else if (base == "f") { *offset_bytes = L.f[l]; *size_bytes = Rl * (size_t)h->cfg.ffn * e; }
     else if (base == "h2") { *offset_bytes = L.h2[l]; *size_bytes = Rl * d * e; }
+    else if (base == "xt") { *offset_bytes = L.xt; *size_bytes = R * (size_t)L.KP * e; }
+    else if (train && base == "rstd1") { *offset_bytes = L.rstd1[l]; *size_bytes = Rl * 4; }          // fp32
+    else if (train && base == "rstd2") { *offset_bytes = L.rstd2[l]; *size_bytes = Rl * 4; }          // fp32
+    else if (train && base == "lse" && !lastl) { *offset_bytes = L.lse[l]; *size_bytes = R * (size_t)h->cfg.heads * 4; }   // fp32
+    else if (train && base == "dP1") { *offset_bytes = L.dP; *size_bytes = R * d * e; }              // norm2-backward outputs (set 1)
+    else if (train && base == "dM1") { *offset_bytes = L.dM; *size_bytes = R * d * e; }
     else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
     else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
     else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }

@@ -32,9 +32,9 @@ constexpr size_t gemm_kl_smem() {
 }
 
 // grid = min(CUs, ceil(M / 128)) persistent blocks of 512 threads
-template <int EPI, int K_, int ABL = 0>
+template <typename T, int EPI, int K_, int ABL = 0>
 __global__ void __launch_bounds__(512) gemm_kl_kernel(const GemmArgs p, const int ntiles) {
-    using T = bf16_t;
+    static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
     static_assert(EPI == EPI_LN || EPI == EPI_ADD, "epilogues with an addend tile");
     constexpr int KS = K_ / 32;                  // k-stages per tile
     constexpr int RST = 4;                       // R-stages per tile (32 rows each)

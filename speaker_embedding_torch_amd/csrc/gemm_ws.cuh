@@ -1,4 +1,4 @@
-// Weight-stationary streaming projection GEMM for the short-K shapes (K = 256: in_proj, FFN1, dF, dO; bf16 mode).
+// Weight-stationary streaming projection GEMM for the short-K shapes (K = 256: in_proj, FFN1, dF, dO; 16-bit storage modes).
 //
 //   C[M, N] = epilogue(A[M, K] . W[N, K]^T)
 //
@@ -38,9 +38,9 @@ constexpr size_t gemm_ws_smem() {
 }
 
 // grid = 8 * (N / 256) * (parts / 8) blocks; `parts` (multiple of 8) row partitions, `ntiles` = ceil(M / 16)
-template <int EPI, int K_>
+template <typename T, int EPI, int K_>
 __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const int parts, const int ntiles) {
-    using T = bf16_t;
+    static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
     constexpr int KGN = K_ / 32;                 // k-groups
     constexpr int ROWB = K_ * 2;                 // bytes per A row
     constexpr int CPR = ROWB / 16;               // 16-byte chunks per A row (32 / 16)
@@ -269,9 +269,9 @@ template <int N, int D> struct WsfWait {
     }
 };
 
-template <int EPI>
+template <typename T, int EPI>
 __global__ void __launch_bounds__(256, 2) gemm_ws_lnbwd_kernel(const GemmArgs p, const LnFuseArgs q, const int parts, const int ntiles) {
-    using T = bf16_t;
+    static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
     static_assert(EPI == EPI_MASK || EPI == EPI_NONE, "consumers of a LayerNorm backward");
     constexpr int KGN = 8, ROWB = 512, ATILE = 16 * ROWB;
     constexpr bool HAS_R = (EPI == EPI_MASK);

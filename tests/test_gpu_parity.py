@@ -9,6 +9,10 @@ Tolerances (north_star: d-vectors within 1e-4 of the CPU reference on the fp32 p
   bf16 path : storage is bf16 (8 mantissa bits) -> d-vector max-abs <= 6e-3 on unit-norm vectors,
               relative L2 <= 2e-2; gradients: cosine >= 0.98 per tensor and relative L2 <= 0.25
               (ReLU masks flip where a pre-activation is within bf16 rounding of zero).
+  fp16 path : storage is IEEE half (11 mantissa bits) -> 8x tighter than bf16: d-vector relative L2 <= 3e-3,
+              gradients (taken under a loss scale, as the reference's GradScaler does) cosine >= 0.999, relative L2 <= 5e-2.
+  16-bit kernels, one by one: tests/test_gpu_kernels_16bit.py checks every kernel of the bf16 / fp16 path against an
+              fp64 evaluation of ITS OWN inputs (the tapped tensors), where the only error left is the output rounding.
 """
 import os
 from argparse import Namespace
@@ -186,6 +190,36 @@ def test_bf16_train_step_vs_oracle(mods, n, t, P, p, tag):
         assert cos > 0.98 and rel_l2(g, r) < 0.25, (name, cos)
 
 
+@pytest.mark.parametrize("n,t,P,p,tag", CASES[:3])
+def test_f16_train_step_vs_oracle(mods, n, t, P, p, tag):
+    """BASELINE.json configs[4]'s arithmetic: float16 storage (the reference's autocast dtype, Train.py:145).  Gradients are
+    taken under a loss scale like GradScaler's (Train.py:153) and compared after unscaling.  Half has 3 more mantissa
+    bits than bf16, so every bound is tighter than the bf16 test's."""
+    GE2E, GE2E_Loss = mods
+    m, params, pe = build(GE2E, "fp16", p)
+    m.train()
+    x_np = O.formula_mel(tag, n, 80, t, logmel=True)
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=p, p_tf=p, pe=pe)
+    loss_ref, lc = O.loss_forward(emb_ref, P)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    emb = m(torch.from_numpy(x_np).cuda())
+    loss = GE2E_Loss().cuda()(emb, P)
+    scale = 4096.0
+    (loss * scale).backward()
+    e = emb.detach().cpu().numpy()
+    assert np.abs(np.linalg.norm(e, axis=1) - 1).max() < 1e-5
+    assert np.abs(e - emb_ref).max() < 1e-3 and rel_l2(e, emb_ref) < 3e-3
+    assert abs(loss.item() - float(loss_ref)) < 3e-3 * max(1.0, abs(float(loss_ref)))
+    for name, prm in m.named_parameters():
+        g, r = (prm.grad.cpu().numpy().ravel() / scale).astype(np.float64), grads_ref[name].ravel().astype(np.float64)
+        assert np.isfinite(g).all(), name
+        if g.size == 1:
+            assert abs(g[0] - r[0]) < 0.03 * np.linalg.norm(grads_ref["prenet.bias"]), name
+            continue
+        cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+        assert cos > 0.999 and rel_l2(g, r) < 5e-2, (name, cos, rel_l2(g, r))
+
+
 @pytest.mark.parametrize("layers", [1, 2])
 def test_fp32_other_layer_counts(mods, layers):
     """Num_Layers is a hyper-parameter: the frame-0-only treatment of the LAST layer must hold for any depth."""
@@ -209,7 +243,7 @@ def test_multislice_inference_fp32_and_bf16(mods):
     """config 4 shape family: `samples` overlapping slices averaged BEFORE projection (Modules.py:55)."""
     GE2E, _ = mods
     x_np = O.formula_mel(8, 5 * 8, 80, 64, logmel=True)
-    for prec, tol in (("fp32", 1e-4), ("bf16", 2e-2)):
+    for prec, tol in (("fp32", 1e-4), ("bf16", 2e-2), ("fp16", 3e-3)):
         m, params, pe = build(GE2E, prec, 0.1)
         m.eval()
         ref, _ = O.encoder_forward(params, x_np, samples=5, pe=pe)
@@ -219,19 +253,23 @@ def test_multislice_inference_fp32_and_bf16(mods):
 
 
 # ------------------------------------------------------------------------------------------ full size properties
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
-def test_full_size_properties(mods, prec):
-    """64 spk x 15 utt x 160 frames: unit norm, finiteness, determinism, batch-independence in eval mode
-    (an utterance's d-vector must not depend on its neighbours), dropout changes with the step counter."""
+@pytest.mark.parametrize("prec,S,P,T", [("bf16", 64, 15, 160), ("fp32", 64, 15, 160),
+                                        ("fp16", 256, 10, 180), ("bf16", 256, 10, 180)])
+def test_full_size_properties(mods, prec, S, P, T):
+    """BASELINE.json's full sizes -- configs[1] 64 spk x 15 utt x 160 frames and configs[4] 256 spk x 10 utt x 180 frames
+    (per GPU; float16 as stated there, and bf16) -- through size-independent properties: unit norm, finiteness, determinism,
+    batch-independence in eval mode (an utterance's d-vector must not depend on its neighbours), an oracle spot check of
+    8 utterances, a full step with finite gradients, and the dropout stream following the step counter."""
     GE2E, GE2E_Loss = mods
     m, params, pe = build(GE2E, prec, 0.1)
+    N = S * P
     g = torch.Generator(device="cuda").manual_seed(7)
-    x = (torch.randn(960, 80, 160, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    x = (torch.randn(N, 80, T, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
     m.eval()
     with torch.no_grad():
         e_full = m(x)
         e_again = m(x)
-        perm = torch.randperm(960, device="cuda", generator=g)
+        perm = torch.randperm(N, device="cuda", generator=g)
         e_perm = m(x[perm].contiguous())
         e_small = m(x[100:120].contiguous())
     assert torch.isfinite(e_full).all()
@@ -241,18 +279,22 @@ def test_full_size_properties(mods, prec):
     assert (e_small - e_full[100:120]).abs().max() < 1e-6
     # spot-check 8 utterances of the big batch against the oracle
     ref, _ = O.encoder_forward(params, x[:8].cpu().numpy(), pe=pe)
-    assert rel_l2(e_full[:8].cpu().numpy(), ref) < (1e-4 if prec == "fp32" else 2e-2)
+    assert rel_l2(e_full[:8].cpu().numpy(), ref) < {"fp32": 1e-4, "bf16": 2e-2, "fp16": 3e-3}[prec]
     # one full training step: finite gradients, loss near the value of the eval embeddings' loss
     m.train()
     crit = GE2E_Loss().cuda()
-    emb1 = m(x); loss1 = crit(emb1, 15); loss1.backward()
+    ls = 1024.0 if prec == "fp16" else 1.0                             # float16 gradients are taken under a loss scale
+    emb1 = m(x); loss1 = crit(emb1, P); (loss1 * ls).backward()
     g1 = torch.cat([p.grad.flatten() for p in m.parameters()])
     assert torch.isfinite(g1).all() and g1.abs().max() > 0
+    # the S-wide softmax loss of the step (S = 256 for configs[4]) against the oracle's loss on the same d-vectors
+    loss_ref, _ = O.loss_forward(emb1.detach().cpu().numpy(), P)
+    assert abs(loss1.item() - float(loss_ref)) < 2e-5 * max(1.0, float(loss_ref))
     emb2 = m(x)                                                        # next step counter -> other masks
     assert (emb1 - emb2).abs().max() > 1e-4
     m.zero_grad()
     m._step = 0
-    emb3 = m(x); crit(emb3, 15).backward()                             # same (seed, step) -> same masks
+    emb3 = m(x); (crit(emb3, P) * ls).backward()                       # same (seed, step) -> same masks
     assert torch.equal(emb3, emb1)
     g3 = torch.cat([p.grad.flatten() for p in m.parameters()])
     assert ((g3 - g1).norm() / g1.norm()).item() < 1e-3                # atomics reorder fp32 sums only

@@ -22,7 +22,10 @@ def write_hp(tmp_path, **over):
     hp = yaml.safe_load(open(HP))
     hp["Checkpoint_Path"] = str(tmp_path / "ckpt")
     hp["Log_Path"] = str(tmp_path / "log")
-    hp["Use_Mixed_Precision"] = over.pop("bf16", False)
+    hp["Use_Mixed_Precision"] = over.pop("bf16", False)         # with the shipped optional key Mixed_Precision_Dtype: 'bf16'
+    mp = over.pop("mp_dtype", None)                              # 'fp16': the reference's autocast dtype (+ GradScaler)
+    if mp is not None:
+        hp["Use_Mixed_Precision"], hp["Mixed_Precision_Dtype"] = True, mp
     p = over.pop("dropout", 0.1)
     hp["GE2E"]["Positional_Encoding"]["Dropout_Rate"] = p
     hp["GE2E"]["Transformer"]["Dropout_Rate"] = p
@@ -244,16 +247,19 @@ def test_fused_clip_adamw_matches_torch():
     ob2.load_state_dict(sa)                                                       # torch loads the fused optimizer's state
 
 
-@pytest.mark.parametrize("bf16", [True, False])
+@pytest.mark.parametrize("bf16", [True, False, "fp16"])
 def test_training_learns_synthetic_speakers(tmp_path, bf16):
     """End to end through Trainer.Train_Step (forward, GE2E loss, backward, clip, AdamW; dropout on): on mel batches whose
     only structure is a per-speaker spectral envelope the loss must fall well below its initial value within 40 steps and
     held-out utterances of a speaker must end up closer to their own centroid than to any other."""
     from speaker_embedding_torch_amd.Train import Trainer
     S, P, T = 8, 6, 64
-    hp_path = write_hp(tmp_path, bf16=bf16, **{"Train.Batch.Train.Speaker": S, "Train.Batch.Train.Pattern_per_Speaker": P,
-                                               "Train.Learning_Rate.Initial": 5e-4})
+    kw = {"mp_dtype": "fp16"} if bf16 == "fp16" else {"bf16": bf16}
+    hp_path = write_hp(tmp_path, **kw, **{"Train.Batch.Train.Speaker": S, "Train.Batch.Train.Pattern_per_Speaker": P,
+                                          "Train.Learning_Rate.Initial": 5e-4})
     tr = Trainer(hp_path, datasets={})
+    assert tr.model.precision == {True: "bf16", False: "fp32", "fp16": "fp16"}[bf16]
+    assert tr.scaler.is_enabled() == (bf16 == "fp16")              # GradScaler(enabled=...) as Train.py:134, float16 only
     g = torch.Generator().manual_seed(0)
     envelopes = torch.randn(S, 80, 1, generator=g) * 1.5                        # what identifies a speaker
 
@@ -272,6 +278,8 @@ def test_training_learns_synthetic_speakers(tmp_path, bf16):
     cent = torch.nn.functional.normalize(e.mean(1), dim=1)
     sim = torch.einsum("spd,cd->spc", e, cent)                                   # [S, P, S]
     assert (sim.argmax(-1) == torch.arange(S)[:, None]).float().mean() > 0.9
+    if bf16 == "fp16":        # the dynamic loss scale settled somewhere finite and most steps were taken
+        assert 1.0 <= tr.scaler.get_scale() <= 65536.0 * 4 and tr.scaler.steps_taken() >= 30
 
 
 def test_loss_scaled_step_matches_torch_gradscaler_semantics():

@@ -39,7 +39,7 @@ __global__ void count_diff(const uint32_t* a, const uint32_t* b, size_t n, unsig
 
 template <int EPI>
 void run_ws(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, double flops, double bytes, int parts) {
-    auto kern = gemm_ws_kernel<EPI, 256>;
+    auto kern = gemm_ws_kernel<bf16_t, EPI, 256>;
     const size_t smem = gemm_ws_smem<EPI, 256>();
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     a.C = C2;
@@ -56,7 +56,7 @@ void run_ws(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, doubl
 
 template <int EPI, int K_, int ABL = 0>
 void run_kl(const char* name, GemmArgs a, bf16_t* Cref, bf16_t* C2, int M, double flops, double bytes, int grid_cap) {
-    auto kern = gemm_kl_kernel<EPI, K_, ABL>;
+    auto kern = gemm_kl_kernel<bf16_t, EPI, K_, ABL>;
     const size_t smem = gemm_kl_smem<EPI>();
     CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
     a.C = C2;
