@@ -8,9 +8,10 @@ by their producers -- the kernel's formula is evaluated in fp64 on them (referen
 Modules.py:46-59 and the autograd of it; dropout masks from the shared counter hash), and the kernel's OUTPUT must be
 that value rounded to the storage type.  Device output and expectation are BOTH rounded values, so they differ only where
 the fp32-vs-fp64 accumulation difference moves a result across a rounding boundary (a small fraction of the elements, by
-one ulp): the bound is a relative L2 of 0.3 x the unit roundoff of the type (attention, whose probabilities go through a
-fast exp2 and an internal rounding: 1 x) and no element further than 3 ulp of the tensor's scale -- an order of magnitude
-below what a wrong term, a missed mask or a mis-addressed ragged row would produce.  Weight gradients (fp32 outputs) get
+one ulp): the bound is a relative L2 of 0.05 x the unit roundoff of the type (observed <= 0.02; attention, whose
+probabilities go through a fast exp2 and an internal rounding: 0.4 x, observed <= 0.15) and no element further than 3 ulp
+of the tensor's scale -- two orders of magnitude below what a wrong term, a missed mask or a mis-addressed ragged row
+would produce (the end-to-end bf16 gradient bound of test_gpu_parity.py is ~60 x the unit roundoff).  Weight gradients (fp32 outputs) get
 2e-4 relative.
 Shapes are ragged on purpose (T = 77: not a multiple of 16; R = 462 rows: not a multiple of any tile)."""
 import os
@@ -37,7 +38,7 @@ def rt(x, prec):
 OBSERVED = []        # (what, relative L2 error in units of the unit roundoff): printed with `pytest -s` to recalibrate the bounds
 
 
-def close(got, ref, prec, what, l2=0.3, ulps=3.0):
+def close(got, ref, prec, what, l2=0.05, ulps=3.0):
     """`got` (device output, already in the storage type) vs `ref` (fp64, NOT yet rounded)."""
     got, want = got.to(F64), rt(ref, prec)
     err = (got - want).norm().item() / max(want.norm().item(), 1e-30)
@@ -122,7 +123,7 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
             pd = rt(prob * keep_a * scale_d, prec)                                                 # P is packed to the storage type for P.V
             o_ref = (pd @ v).permute(0, 2, 1, 3).reshape(R, d)
         o = tap(f"o.{l}", (Rl, d))
-        close(o, o_ref, prec, f"attention forward layer {l}", l2=1.0, ulps=4.0)
+        close(o, o_ref, prec, f"attention forward layer {l}", l2=0.4, ulps=4.0)
         if not last:
             lse = tap(f"lse.{l}", (R, heads), torch.float32)
             lse_ref = torch.logsumexp(s, dim=-1).permute(0, 2, 1).reshape(R, heads)
@@ -216,7 +217,7 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     dq, dk, dv = ds @ sv["k"], ds.transpose(-1, -2) @ sv["q"], pdr.transpose(-1, -2) @ do_h
     dqkv_ref = torch.cat([z.permute(0, 2, 1, 3).reshape(R, d) for z in (dq, dk, dv)], dim=1)
     dQKV = tap("dQKV", (R, 3 * d))
-    close(dQKV, dqkv_ref, prec, "attention backward (attn_bwd_kernel)", l2=1.0, ulps=6.0)
+    close(dQKV, dqkv_ref, prec, "attention backward (attn_bwd_kernel)", l2=0.4, ulps=6.0)
     wclose(pre + "self_attn.in_proj_weight", dQKV.t() @ sv["h_in"]); wclose(pre + "self_attn.in_proj_bias", dQKV.sum(0))
     dHa = tap("dHa", (R, d))
     close(dHa, dP2 + dQKV @ W[pre + "self_attn.in_proj_weight"], prec, "dH = dPre1 + dQKV Win (gemm_nt EPI_ADD, K = 768)")
