@@ -39,7 +39,7 @@ PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}            # dense MFMA T
 DTYPE_NAME = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}
 HBM_PEAK_GBS = 8000.0                             # HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
-                    "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD}
+                    "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD, "ffn": _lib.K_FFN}
 
 
 def synth_mel(n, mel, t, seed, device):
@@ -304,7 +304,8 @@ def main():
             roofline = {
                 "bound": "hbm" if hbm_bound else "mfma",
                 "kernel": {"gemm": "projection GEMM class: gemm_ws_kernel / gemm_ws_lnbwd_kernel (K=256) + gemm_nt_kernel<128x128>", "gemm_ln": "LayerNorm GEMMs: gemm_ws_kernel<LN> + gemm_kl_kernel<LN>", "wgrad": "wgrad_kernel",
-                           "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel"}[args.roofline_kernel],
+                           "attn_fwd": "attn_fwd_kernel", "attn_bwd": "attn_bwd_kernel",
+                           "ffn": "ffn_chain_kernel (FFN1 + ReLU + dropout + FFN2 + residual + LayerNorm)"}[args.roofline_kernel],
                 "achieved": round(gbs if hbm_bound else tf, 2), "peak": HBM_PEAK_GBS if hbm_bound else PEAK[args.precision],
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / PEAK[args.precision]), 4),

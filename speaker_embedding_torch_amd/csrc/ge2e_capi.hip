@@ -17,6 +17,7 @@
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
+#include "ffn.cuh"
 #include "misc.cuh"
 #include "melfront.cuh"
 
@@ -319,6 +320,29 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a);
 }
 
+// FFN1 -> ReLU -> dropout -> FFN2 -> dropout -> residual -> LayerNorm in one launch (ffn.cuh): 16-bit modes, full-height layers.
+// The choice never depends on M (a row's result must not depend on the batch it sits in): every non-last layer takes it.
+inline bool ffn_chain_on() { static const bool off = getenv("GE2E_NO_FFN_CHAIN") != nullptr; return !off; }
+template <typename T>
+int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
+    if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "ffn chain: 16-bit modes only");
+    else {
+        const int npass = (a.M + 255) / 256;
+        if (h->num_cus <= 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device >= 0 ? h->device : 0) != hipSuccess || n <= 0) n = 256;
+            h->num_cus = n;
+        }
+        const int grid = std::min(h->num_cus, npass);
+        const double rows = a.M;
+        const double abytes = 2.0 * (rows * 256 * 2 + (a.Fo ? rows * FFN_F : 0.0) + 2.0 * 256 * FFN_F);
+        ProfScope ps(h, st, GE2E_K_FFN, 2.0 * rows * 256 * FFN_F * 2.0, abytes);
+        if (a.Fo) { auto kern = ffn_chain_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem(), st, a, npass); }
+        else { auto kern = ffn_chain_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem(), st, a, npass); }
+        return 0;
+    }
+}
+
 template <typename T, int XLOAD>
 int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
     constexpr int RS = 2 * Prec<T>::KG;
@@ -584,6 +608,18 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.drow_mul = rmul;
             CK(gemm_ln<T>(h, st, a));
+        }
+        if (sizeof(T) == 2 && !last && c.ffn == FFN_F && d == 256 && ffn_chain_on()) {
+            // linear1 + ReLU + dropout + linear2 + dropout2 + residual + norm2, the hidden on chip (written once in train mode)
+            FfnArgs a{};
+            a.A = ws + L.h1[l]; a.lda = d; a.W1 = ws + L.w_l1[l]; a.b1 = P[lp(l, L_L1_B)]; a.W2 = ws + L.w_l2[l]; a.b2 = P[lp(l, L_L2_B)];
+            a.Fo = train ? ws + L.f[l] : nullptr; a.ldf = c.ffn; a.C = ws + L.h2[l]; a.ldc = d;
+            a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)]; a.eps = c.ln_eps;
+            a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
+            a.drop1 = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
+            a.drop2 = make_drop(train, c.tf_dropout, seed, step, site_ff(l)); a.drow_mul = rmul; a.M = Rl;
+            CK(launch_ffn_chain<T>(h, st, a));
+            continue;
         }
         {   // linear1 + ReLU + dropout
             GemmArgs a{};
