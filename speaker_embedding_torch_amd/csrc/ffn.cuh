@@ -10,7 +10,8 @@
 //   * a wave keeps ITS 32 rows of h1 in registers as MFMA operand fragments for the whole pass (2 row tiles x 8 k-groups x 16 B
 //     = 64 VGPRs) and its 32 x 256 output accumulators (128 VGPRs); nothing of the activations lives in LDS;
 //   * the weights stream through a 4-slot LDS ring by LDS-DMA (global_load_lds, 16 B / lane), three stages ahead, behind a
-//     counted s_waitcnt vmcnt(N) and one raw s_barrier per stage.  A stage is 32 hidden units: the W1 slice [32][256] (16 KB)
+//     counted s_waitcnt vmcnt(N) and one raw s_barrier per stage (placed between the two products of a stage: it publishes
+//     the NEXT stage, whose first fragments are then prefetched under this stage's last MFMAs).  A stage is 32 hidden units: the W1 slice [32][256] (16 KB)
 //     and the W2 slice [256][32] (16 KB), shared by the 8 waves; the stream is the same for every pass and never drains;
 //   * per stage and wave: 32 MFMAs h[32 rows][32 hidden] = h1 . W1c^T, then bias + ReLU + dropout in registers, then the
 //     accumulator tiles are packed straight into the operand of the next 32 MFMAs out += hidden . W2c^T (guide 3, "an
@@ -47,8 +48,11 @@ constexpr int FFN_SLOT = 32 * 1024;
 constexpr int FFN_F = 1024;        // hidden width (4 x 256)
 constexpr size_t ffn_smem() { return (size_t)FFN_NSTG * FFN_SLOT + (FFN_F + 3 * 256) * 4; }
 
-// grid = min(CUs, ceil(M / 256)) persistent blocks of 512 threads
-template <typename T, bool STORE_F>
+// grid = persistent blocks of 512 threads, one per CU at most, sized so that every block runs the same number of passes
+// ABL (development only, tools/ffn_bench.hip): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no barrier, 16 no hidden epilogue
+// STAGGER: waves 4-7 lag by one product (see the stage loop).  Measured at 153,600 rows: train (dropout hashes + hidden store in the
+// hidden epilogue) 310 -> 279 us with it, eval (a light epilogue) 215 -> 243 us: the launcher staggers train mode only.
+template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F>
 __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const int npass) {
     static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
     constexpr int NCH = FFN_F / 32;              // stages per pass
@@ -63,6 +67,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
+    const bool lag = STAGGER && wave >= 4;       // wave-uniform (wave comes from readfirstlane)
     const int G = gridDim.x, b = blockIdx.x;
     const int my = b < npass ? (npass - b + G - 1) / G : 0;
     if (my == 0) return;
@@ -74,22 +79,22 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     const unsigned char* const W1g = (const unsigned char*)p.W1;
     const unsigned char* const W2g = (const unsigned char*)p.W2;
     // ---- producer: the weight stream (stage s carries hidden units 32 (s % NCH) .. +31)
+    // per-lane source offsets (32-bit, loop-invariant) on top of wave-uniform bases.  One VGPR per table: the second
+    // instruction of a wave covers W1 rows + 2 (same swizzle with bit 1 of the row flipped: chunk ^ 2, + 1024 B) and W2 rows + 16
+    // (same swizzle: a wave-uniform + 16 rows).
+    const int dr1 = 4 * wave + (lane >> 5);
+    const unsigned dma1 = (unsigned)(dr1 * 512 + (((lane & 31) ^ (((dr1 >> 3) << 2) | (dr1 & 3))) << 4));    // W1 slice row dr1, swizzled chunk (= the lane index i that reads it)
+    const unsigned dma2 = (unsigned)((32 * wave + (lane >> 2)) * (FFN_F * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));   // W2 row 32 w + r2, chunk pos ^ ((r2 >> 2) & 3)
     int i_c = 0, i_slot = 0;
     auto issue = [&]() {
         unsigned char* const slot = Ring + i_slot * FFN_SLOT;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {            // W1 slice: 16 instructions of 2 rows x 512 B; this wave: 2w, 2w + 1
-            const int id = 2 * wave + u;
-            const int r = 2 * id + (lane >> 5), pos = lane & 31;
-            const int c = pos ^ (((r >> 3) << 2) | (r & 3));          // swizzle = the lane index i that reads row r (below)
-            glds16(W1g + ((size_t)(i_c * 32 + r) * 256) * 2 + c * 16, slot + id * 1024);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {            // W2 slice: 16 instructions of 16 rows x 64 B
-            const int id = 2 * wave + u;
-            const int r = lane >> 2;
-            const int c = (lane & 3) ^ ((lane >> 4) & 3);             // pos ^ ((r >> 2) & 3)
-            glds16(W2g + ((size_t)(16 * id + r) * FFN_F + i_c * 32) * 2 + c * 16, slot + 16384 + id * 1024);
+        if constexpr ((ABL & 2) == 0) {
+        const unsigned char* const s1 = W1g + (size_t)i_c * (32 * 512);       // wave-uniform: hidden units 32 i_c ..
+        const unsigned char* const s2 = W2g + (size_t)i_c * 64;
+        glds16(s1 + dma1, slot + (2 * wave) * 1024);                                   // rows 4w, 4w + 1 (512 B each)
+        glds16(s1 + ((dma1 ^ 32u) + 1024u), slot + (2 * wave + 1) * 1024);             // rows 4w + 2, 4w + 3
+        glds16(s2 + dma2, slot + 16384 + (2 * wave) * 1024);                           // 16 rows x 64 B
+        glds16(s2 + 16 * (FFN_F * 2) + dma2, slot + 16384 + (2 * wave + 1) * 1024);    // the next 16 rows
         }
         if (++i_c == NCH) i_c = 0;
         if (++i_slot == NSTG) i_slot = 0;
@@ -97,22 +102,57 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll 1
     for (int q = 0; q < D; ++q) issue();
 
-    // fragment read addresses (bytes inside a slot).  Lane (i, g) of hidden tile ht reads W1 row 8 (i >> 2) + 4 ht + (i & 3):
-    // its accumulator rows 4g + r are then hidden units 8g + 4 ht + r, i.e. tiles 0 and 1 together hold the 8 CONSECUTIVE
-    // units 8g .. 8g + 7.  Lane (i, g) of output tile 2 kg + h reads W2 row 32 kg + 8 (i >> 2) + 4 h + (i & 3): accumulator rows
-    // 4g + r are output columns 32 kg + 8g + 4h + r -- the columns of this lane's h1 fragment af[.][kg].
+    // fragment read addresses.  Lane (i, g) of hidden tile ht reads W1 row 8 (i >> 2) + 4 ht + (i & 3): its accumulator rows
+    // 4g + r are then hidden units 8g + 4 ht + r, i.e. tiles 0 and 1 together hold the 8 CONSECUTIVE units 8g .. 8g + 7.  Lane
+    // (i, g) of output tile 2 kg + h reads W2 row 32 kg + 8 (i >> 2) + 4 h + (i & 3): accumulator rows 4g + r are output columns
+    // 32 kg + 8g + 4h + r -- the columns of this lane's h1 fragment af[.][kg].
+    // Every address is (one of six lane-dependent bases) + (a compile-time constant that fits the ds_read offset field):
+    //   W1 (kg, ht): chunk position (4 kg + g) ^ i = 16 (kg >> 2) + 4 ((kg & 3) ^ (i >> 2)) + (g ^ (i & 3))
+    //                -> base w1b[kg & 3] + 2048 ht + 256 (kg >> 2)
+    //   W2 (kg, h) : base w2b[h] + 2048 kg
+    // (32 separately materialised lane addresses would not fit the register file next to 192 accumulator / operand registers.)
     const int w1row = 8 * (i >> 2) + (i & 3);
-    int w2o[2];                                                                       // + 2048 kg
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)       // row r = 8 (i >> 2) + 4 hh + (i & 3) of a 16-row DMA piece sits at chunk position g ^ ((r >> 2) & 3)
-        w2o[hh] = 16384 + (w1row + 4 * hh) * 64 + ((g ^ ((2 * ((i >> 2) & 1) + hh) & 3)) << 4);
+    const unsigned w1c = (unsigned)(w1row * 512 + ((g ^ (i & 3)) << 4));                      // W1: + ((kq ^ (i >> 2)) << 6) per k-group class
+    // W2 row r = 8 (i >> 2) + 4 hh + (i & 3) of a 16-row DMA piece sits at chunk position g ^ ((r >> 2) & 3) = g ^ (2 ((i >> 2) & 1) + hh):
+    // hh = 1 is hh = 0 with chunk bit 0 flipped (^ 16 B) and 4 rows (256 B) further
+    const unsigned w2c = (unsigned)(16384 + w1row * 64 + ((g ^ (2 * ((i >> 2) & 1))) << 4));
 
+    auto mm = [&](const u32x4& w, const u32x4& a, f32x4 acc) -> f32x4 {
+        if constexpr (ABL & 1) { asm volatile("" :: "v"(w), "v"(a)); return acc; }
+        else return mma16<T>(w, a, acc);
+    };
     const unsigned char* const Ag = (const unsigned char*)p.A;
     T* const Cg = (T*)p.C;
     T* const Fg = (T*)p.Fo;
     const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
     const int last_row = p.M - 1;
     int c_slot = 0;
+    float oacc_sink = 0.0f;                           // ABL 64 only
+
+    // W1 fragments of k-group kg from the stage whose bases are a1[]: [0] hidden tile 0, [1] hidden tile 1
+    auto read_w1 = [&](const unsigned* a1, int kg, u32x4* w) {
+#pragma unroll
+        for (int ht = 0; ht < 2; ++ht) {
+            if constexpr (ABL & 4) { w[ht] = u32x4{a1[kg & 3], a1[0], a1[1], (unsigned)kg}; asm volatile("" : "+v"(w[ht])); }
+            else w[ht] = lds16(smem + a1[kg & 3] + (ht * 2048 + (kg >> 2) * 256));
+        }
+    };
+    // W2 fragments of output tiles 2q, 2q + 1
+    auto read_w2 = [&](const unsigned* a2, int q, u32x4* w) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if constexpr (ABL & 4) { w[hh] = u32x4{a2[hh], a2[0], a2[1], (unsigned)q}; asm volatile("" : "+v"(w[hh])); }
+            else w[hh] = lds16(smem + a2[hh] + q * 2048);
+        }
+    };
+    // this stage's bases = lane part + slot offset, made opaque so that the constants stay in the instructions' offset fields
+    auto stage_bases = [&](int slot_index, unsigned* a1, unsigned* a2) {
+        const unsigned so = (unsigned)slot_index * FFN_SLOT;
+#pragma unroll
+        for (int kq = 0; kq < 4; ++kq) { a1[kq] = w1c + so + (unsigned)((kq ^ (i >> 2)) << 6); asm volatile("" : "+v"(a1[kq])); }
+        a2[0] = w2c + so; a2[1] = ((w2c ^ 16u) + 256u) + so;
+        asm volatile("" : "+v"(a2[0]), "+v"(a2[1]));
+    };
 
 #pragma unroll 1
     for (int ps = 0; ps < my; ++ps) {
@@ -122,16 +162,21 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             int gr = m0 + 16 * rt + i; gr = gr < last_row ? gr : last_row;
+            const unsigned char* arow = Ag + (size_t)gr * p.lda * 2 + g * 16;
+            asm volatile("" : "+v"(arow));
 #pragma unroll
-            for (int kg = 0; kg < 8; ++kg) af[rt][kg] = *(const u32x4*)(Ag + (size_t)gr * p.lda * 2 + kg * 64 + g * 16);
+            for (int kg = 0; kg < 8; ++kg) af[rt][kg] = *(const u32x4*)(arow + kg * 64);
         }
         // retire these ordinary loads HERE (and with them everything older): the stage loop then contains no load the compiler
-        // has to wait for, so its own waits stay out of it, and the counted waits below may assume the steady state from stage 0
+        // has to wait for, so its own waits stay out of it, and the counted wait below may assume the steady state from stage 0
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) asm volatile("" : "+v"(af[rt][kg]));
         wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();             // every wave's pieces of the next D stages have landed
+        __builtin_amdgcn_sched_barrier(0);
 
         f32x4 oacc[2][16];
 #pragma unroll
@@ -139,63 +184,148 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) oacc[rt][nt] = f32x4{0, 0, 0, 0};
 
-#pragma unroll 1
-        for (int c = 0; c < NCH; ++c) {
-            // stage c has landed once at most the (D-1) younger stages' DMAs and the D stages' worth of hidden stores issued
-            // since are outstanding; everyone is done with the slot refilled below (its fragments were consumed a stage ago)
-            wait_vmcnt<(D - 1) * NDMA + D * NST>();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            issue();
-            const unsigned char* const slot = Ring + c_slot * FFN_SLOT;
-            if (++c_slot == NSTG) c_slot = 0;
+        // The fragment reads run one group (2 fragments = 4 MFMAs) ahead of the matrix pipe: wA / wB alternate, and every
+        // product ends by reading the first fragments of the product that follows it in program order into wA.
+        //
+        // The two waves of a SIMD (w and w + 4) run the three pieces of a stage -- product 1, hidden epilogue, product 2 -- in
+        // DIFFERENT phase: waves 4-7 lag by one product (their product 2 of stage c runs at the top of iteration c + 1), so
+        // that between two barriers one wave of a SIMD is on the vector ALU / LDS while its partner feeds the matrix pipe.
+        // In lockstep both would issue MFMAs at the same time and then both sit in the epilogue (measured: the MFMA time and
+        // everything else simply add up).  Barrier protocol and slot reuse are unchanged: every read of a slot still falls
+        // between the barrier that published it and the barrier before its refill.
+        u32x4 wA[2], wB[2];
+        unsigned a1[4], a2[2];
+        stage_bases(c_slot, a1, a2);
+        read_w1(a1, 0, wA);
 
-            // ---- product 1: h[rt][ht] = h1 rows . W1 slice^T   (K = 256)
-            f32x4 h[2][2];
+        // product 1 of the stage with bases (b1, b2); ends with the first W2 fragments of the same stage in wA
+        auto prod1 = [&](f32x4 (&h)[2][2], const unsigned* b1, const unsigned* b2) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) { h[rt][0] = f32x4{0, 0, 0, 0}; h[rt][1] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) {
+                u32x4* const cur = (kg & 1) ? wB : wA;
+                u32x4* const nxt = (kg & 1) ? wA : wB;
+                if (kg < 7) read_w1(b1, kg + 1, nxt);
+                else read_w2(b2, 0, nxt);            // kg == 7: nxt == wA
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht) {
-                    const u32x4 wf = lds16(slot + (w1row + 4 * ht) * 512 + (((kg * 4 + g) ^ i) << 4));
-                    h[0][ht] = mma16<T>(wf, af[0][kg], h[0][ht]);
-                    h[1][ht] = mma16<T>(wf, af[1][kg], h[1][ht]);
+                    h[0][ht] = mm(cur[ht], af[0][kg], h[0][ht]);
+                    h[1][ht] = mm(cur[ht], af[1][kg], h[1][ht]);
                 }
-                if (kg & 1) __builtin_amdgcn_sched_barrier(0);     // bound the live range of the weight fragments (4 reads in flight)
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // ---- bias + ReLU + dropout in registers; the packed tiles are the hidden's storage-type values
-            u32x4 hp[2];
+        };
+        // bias + ReLU + dropout in registers; the packed tiles are the hidden's storage-type values (and product 2's operand)
+        auto hidden_epilogue = [&](f32x4 (&h)[2][2], u32x4* hp, int c) {
+            unsigned bb = (unsigned)(NSTG * FFN_SLOT) + (unsigned)(c * 128 + 32 * g);      // &B1s[32 c + 8 g], opaque: constants stay in the offset field
+            asm volatile("" : "+v"(bb));
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int row = m0 + 16 * rt + i;
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht) {
                     const int col = c * 32 + 8 * g + 4 * ht;
-                    h[rt][ht] += *(const f32x4*)(B1s + col);
+                    if constexpr ((ABL & 16) == 0) {
+                    h[rt][ht] += *(const f32x4*)(smem + bb + 16 * ht);
                     (void)relu_drop_apply4(p.drop1, (uint32_t)row * drm * (uint32_t)FFN_F + (uint32_t)col, h[rt][ht]);
+                    }
                 }
                 hp[rt] = pack_acc<T>(h[rt][0], h[rt][1]);      // 8 consecutive hidden units 32c + 8g .. + 7 of row (rt, i)
                 if constexpr (STORE_F) {
                     if (row < p.M) __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + ((size_t)row * p.ldf + c * 32 + 8 * g) * 2));
                 }
             }
-            // ---- product 2: out[rt][nt] += hidden . W2 slice^T   (K = these 32 hidden units, one MFMA deep)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // product 2 with the W2 bases b2; ends with the first W1 fragments of the stage whose bases are nb1 in wA
+        auto prod2 = [&](const u32x4* hp, const unsigned* b2, const unsigned* nb1) {
 #pragma unroll
-            for (int nt = 0; nt < 16; ++nt) {
-                const u32x4 wf = lds16(slot + w2o[nt & 1] + (nt >> 1) * 2048);
-                oacc[0][nt] = mma16<T>(wf, hp[0], oacc[0][nt]);
-                oacc[1][nt] = mma16<T>(wf, hp[1], oacc[1][nt]);
-                if ((nt & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            for (int q = 0; q < 8; ++q) {
+                u32x4* const cur = (q & 1) ? wB : wA;
+                u32x4* const nxt = (q & 1) ? wA : wB;
+                if (q < 7) read_w2(b2, q + 1, nxt);
+                else read_w1(nb1, 0, nxt);           // q == 7: nxt == wA
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    oacc[0][2 * q + hh] = mm(cur[hh], hp[0], oacc[0][2 * q + hh]);
+                    oacc[1][2 * q + hh] = mm(cur[hh], hp[1], oacc[1][2 * q + hh]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+
+        // stage c + 1 must be complete before anyone reads from it, and the slot of stage c - 1 is refilled: this wave's pieces
+        // of stage c + 1 have landed once at most the (D-2) younger stages' DMAs and the (D-1) stages' worth of hidden stores
+        // issued since are outstanding
+        auto publish_next = [&]() {
+            wait_vmcnt<(D - 2) * NDMA + (D - 1) * NST>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        constexpr int NCHR = (ABL & 32) ? 0 : NCH;
+        if (!lag) {
+#pragma unroll 1
+            for (int c = 0; c < NCHR; ++c) {
+                f32x4 h[2][2];
+                u32x4 hp[2];
+                unsigned n1[4], n2[2];
+                prod1(h, a1, a2);
+                publish_next();
+                hidden_epilogue(h, hp, c);
+                c_slot = c_slot + 1 == NSTG ? 0 : c_slot + 1;
+                stage_bases(c_slot, n1, n2);
+                prod2(hp, a2, n1);
+#pragma unroll
+                for (int kq = 0; kq < 4; ++kq) a1[kq] = n1[kq];
+                a2[0] = n2[0]; a2[1] = n2[1];
+            }
+        } else if (NCHR > 0) {
+            u32x4 hp[2];
+            unsigned pa2[2];
+            {   // stage 0: no product 2 is pending yet
+                f32x4 h[2][2];
+                publish_next();
+                prod1(h, a1, a2);
+                hidden_epilogue(h, hp, 0);
+                pa2[0] = a2[0]; pa2[1] = a2[1];
+                c_slot = c_slot + 1 == NSTG ? 0 : c_slot + 1;
+                stage_bases(c_slot, a1, a2);
+            }
+#pragma unroll 1
+            for (int c = 1; c < NCHR; ++c) {
+                f32x4 h[2][2];
+                prod2(hp, pa2, a1);                // product 2 of stage c - 1, then the first W1 fragments of stage c
+                publish_next();
+                prod1(h, a1, a2);
+                hidden_epilogue(h, hp, c);
+                pa2[0] = a2[0]; pa2[1] = a2[1];
+                c_slot = c_slot + 1 == NSTG ? 0 : c_slot + 1;
+                stage_bases(c_slot, a1, a2);
+            }
+            prod2(hp, pa2, a1);                    // the last stage's product 2 (its trailing fragment read is not used)
         }
 
+        if constexpr (ABL & 64) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < 16; ++nt) oacc_sink += oacc[rt][nt][0] + oacc[rt][nt][1] + oacc[rt][nt][2] + oacc[rt][nt][3];
+        }
         // ---- pass epilogue: v = residual + drop2(out + b2); LayerNorm over the row (this lane: 64 of its 256 columns, the
         // other three quarters sit on the lanes with the same i); rows leave as 16-byte pieces per lane (64 B per row and kg)
+        // (addresses: ONE lane-dependent base per table / row, made opaque inside the pass loop -- otherwise the compiler hoists
+        // ~100 separately materialised addresses out of the pass loop and spills them around the stage loop)
+        unsigned lb = (unsigned)(NSTG * FFN_SLOT + FFN_F * 4) + (unsigned)(32 * g);          // &Ls[8 g]
+        asm volatile("" : "+v"(lb));
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < ((ABL & 64) ? 0 : 2); ++rt) {
             const int row = m0 + 16 * rt + i;
+            unsigned char* crow = (unsigned char*)Cg + ((size_t)row * p.ldc + 8 * g) * 2;
+            asm volatile("" : "+v"(crow));
             float sm = 0.0f;
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) {
@@ -203,7 +333,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int col = 32 * kg + 8 * g + 4 * hh;
-                    f32x4 v = oacc[rt][2 * kg + hh] + *(const f32x4*)(Ls + col);
+                    f32x4 v = oacc[rt][2 * kg + hh] + *(const f32x4*)(smem + lb + (32 * kg + 4 * hh) * 4);
                     drop_apply4(p.drop2, (uint32_t)row * drm * 256u + (uint32_t)col, v);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += to_f32(res[4 * hh + r]);
@@ -225,15 +355,15 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int col = 32 * kg + 8 * g + 4 * hh;
-                    const f32x4 ga = *(const f32x4*)(Ls + 256 + col), be = *(const f32x4*)(Ls + 512 + col);
+                    const f32x4 ga = *(const f32x4*)(smem + lb + 1024 + (32 * kg + 4 * hh) * 4), be = *(const f32x4*)(smem + lb + 2048 + (32 * kg + 4 * hh) * 4);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o2[hh][r] = (oacc[rt][2 * kg + hh][r] - mean) * rs * ga[r] + be[r];
                 }
-                if (row < p.M)
-                    __builtin_nontemporal_store(pack_acc<T>(o2[0], o2[1]), (u32x4*)((unsigned char*)Cg + ((size_t)row * p.ldc + 32 * kg + 8 * g) * 2));
+                if (row < p.M) __builtin_nontemporal_store(pack_acc<T>(o2[0], o2[1]), (u32x4*)(crow + 64 * kg));
             }
         }
     }
+    if constexpr (ABL & 64) { if (p.M < 0) { Cg[tid] = from_f32<T>(oacc_sink); } }
     wait_vmcnt<0>();                                  // the D stages issued past the end land before the block's LDS is released
 }
 
