@@ -73,7 +73,8 @@ int64_t ge2e_param_total(ge2e_handle h);
 
 /* Bytes of caller-owned scratch for n_utts x frames.  train != 0 keeps the activations backward needs. */
 size_t ge2e_workspace_bytes(ge2e_handle h, int n_utts, int frames, int train);
-/* Longest frames count the attention kernels were instantiated for. */
+/* Longest frame count accepted: min(1024, max_position).  Up to 288 frames a head's sequence is LDS-resident (the tuned path:
+ * the reference trains on <= 270 frames and infers on 64 / 240); longer inputs take chunked streaming kernels. */
 int ge2e_max_frames(ge2e_handle h);
 
 /* mel:    device fp32 [n_utts, mel_dim, frames]  (channels-first, as Datasets.Collater produces, Datasets.py:84)

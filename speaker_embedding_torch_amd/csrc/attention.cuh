@@ -306,6 +306,251 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long sequences (288 < T <= Max_Position 1024; reference Modules.py:107-109 slices pe[:, :, :T] for any T up to Max_Position).
+// The kernels above keep a head's whole K / V (or Q / dO) sequence in LDS and a query's whole score row in registers; beyond 288
+// frames neither fits.  These stream the other side through LDS in chunks of 64 rows instead:
+//   attn_fwd_long_kernel   : block = 64 queries (4 waves x 16) of one (utterance, head); K / V chunks; online softmax
+//                            (running raw maximum m, per-lane partial sum l, O rescaled by exp((m_old - m_new) scale)); the
+//                            dropout acts on the normalised probabilities, so the unnormalised e . keep / (1 - p) is
+//                            accumulated and the division by the final sum comes last (linear).  Writes lse.
+//   attn_bwd_long_dq_kernel: block = 64 queries; phase A of attn_bwd_kernel over K / V chunks; also writes delta = dO . O.
+//   attn_bwd_long_dkv_kernel: block = 64 keys; phase B over Q / dO chunks (lse, delta per chunk in LDS); dropout keep bits re-hashed.
+// Same dropout counters as the resident kernels: ((n H + h) T + query) T4 + key.  Functional path (the reference trains on <= 270
+// frames and infers on 64 / 240): not tuned.
+// ---------------------------------------------------------------------------------------------
+constexpr int ATT_LC = 64;       // chunk rows
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_fwd_long_kernel(const AttnArgs p) {
+    using G = attn::Geo<T>;
+    constexpr int NT16 = ATT_LC / 16, KG = Prec<T>::KG, NG = ATT_LC / KG;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_LC * G::LD];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_LC * G::LD];
+    const int bx = blockIdx.x, n = bx / p.H, h = bx % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const size_t ldq = (size_t)3 * p.D * sizeof(T);
+    const unsigned char* base = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
+    const int qrow = blockIdx.y * ATT_LC + 16 * wave + i;
+    const bool vq = qrow < p.T;
+    u32x4 qf[G::NKG];
+    attn::load_row_frags<T>(qf, base, ldq, qrow, vq, g);
+    const float ck = p.scale * ExpK<T>::K;
+    const uint32_t ibase = ((uint32_t)bx * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
+    float m = -INFINITY, lsum = 0.0f;
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
+    for (int c0 = 0; c0 < p.T; c0 += ATT_LC) {
+        __syncthreads();                                   // everyone is done with the previous chunk
+        attn::load_tile<T>(Ks, base + (size_t)p.D * sizeof(T) + (size_t)c0 * ldq, ldq, p.T - c0, ATT_LC);
+        attn::load_tile<T>(Vs, base + (size_t)2 * p.D * sizeof(T) + (size_t)c0 * ldq, ldq, p.T - c0, ATT_LC);
+        __syncthreads();
+        f32x4 s[NT16];
+        float cmax = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            s[t] = attn::tile_dot<T>(Ks, t, qf, i, g);    // S^T[key c0 + 16t + 4g + r][query]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (c0 + 16 * t + 4 * g + r >= p.T) s[t][r] = -INFINITY;
+                cmax = fmaxf(cmax, s[t][r]);
+            }
+        }
+        cmax = cross4_max(cmax);
+        const float mnew = fmaxf(m, cmax);                 // finite: every chunk holds at least one real key
+        const float alpha = ExpK<T>::ex((m - mnew) * ck);  // first chunk: exp(-inf) = 0
+        const float mk = mnew * ck;
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float e = ExpK<T>::ex(s[t][r] * ck - mk); s[t][r] = e; sum += e; }
+            drop_apply4(p.drop, ibase + (uint32_t)(c0 + 16 * t + 4 * g), s[t]);
+        }
+        lsum = lsum * alpha + sum;
+        m = mnew;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] *= alpha;
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                oacc[dt] = mma16<T>(frag_tr<T>(Vs, G::LD, gi * KG, dt * 16, lane), pb, oacc[dt]);
+        }
+    }
+    const float tot = cross4_sum(lsum);
+    const float inv = 1.0f / tot;
+    if (vq) {
+        if (p.lse && g == 0) p.lse[((size_t)n * p.T + qrow) * p.H + h] = m * p.scale + logf(tot);
+        T* orow = (T*)p.o + ((size_t)n * p.T + qrow) * p.D + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(orow + dt * 16, oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+    }
+}
+
+struct AttnLongBwd { float* delta; };     // [R, H] fp32: dO . O per (row, head), written by the dQ kernel, read by the dK / dV kernel
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_long_dq_kernel(const AttnArgs p, const AttnLongBwd x) {
+    using G = attn::Geo<T>;
+    constexpr int KG = Prec<T>::KG, NG = ATT_LC / KG, TPG = KG / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[ATT_LC * G::LD];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[ATT_LC * G::LD];
+    const int bx = blockIdx.x, n = bx / p.H, h = bx % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const size_t ldq = (size_t)3 * p.D * sizeof(T), ldo = (size_t)p.D * sizeof(T);
+    const unsigned char* qbase = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
+    const unsigned char* dobase = (const unsigned char*)p.dout + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
+    const unsigned char* obase = (const unsigned char*)p.o + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
+    const int qrow = blockIdx.y * ATT_LC + 16 * wave + i;
+    const bool vq = qrow < p.T;
+    u32x4 qf[G::NKG], dof[G::NKG];
+    attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
+    attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
+    float delta = 0.0f;
+    {
+        u32x4 of[G::NKG];
+        attn::load_row_frags<T>(of, obase, ldo, qrow, vq, g);
+#pragma unroll
+        for (int k = 0; k < G::NKG; ++k) {
+            const T* a = (const T*)&dof[k];
+            const T* b = (const T*)&of[k];
+#pragma unroll
+            for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
+        }
+    }
+    delta = cross4_sum(delta);
+    const size_t sidx = ((size_t)n * p.T + (vq ? qrow : 0)) * p.H + h;
+    if (vq && g == 0) x.delta[sidx] = delta;
+    const float lse = vq ? p.lse[sidx] * ExpK<T>::K : 0.0f;
+    const float ck = p.scale * ExpK<T>::K;
+    const uint32_t ibase = ((uint32_t)bx * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
+    const bool dropping = p.drop.thr != 0;
+    f32x4 qacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) qacc[dt] = f32x4{0, 0, 0, 0};
+    for (int c0 = 0; c0 < p.T; c0 += ATT_LC) {
+        __syncthreads();
+        attn::load_tile<T>(Ks, qbase + (size_t)p.D * sizeof(T) + (size_t)c0 * ldq, ldq, p.T - c0, ATT_LC);
+        attn::load_tile<T>(Vs, qbase + (size_t)2 * p.D * sizeof(T) + (size_t)c0 * ldq, ldq, p.T - c0, ATT_LC);
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x4 ds[2];
+#pragma unroll
+            for (int u = 0; u < TPG; ++u) {
+                const int t = gi * TPG + u;
+                const f32x4 sa = attn::tile_dot<T>(Ks, t, qf, i, g);
+                f32x4 dp = attn::tile_dot<T>(Vs, t, dof, i, g);
+                if (dropping) {
+                    const uint32_t mk = drop_mask4(p.drop, ibase + (uint32_t)(c0 + 16 * t + 4 * g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = ((mk >> r) & 1u) ? dp[r] * p.drop.scale : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float pr = ExpK<T>::ex(sa[r] * ck - lse);
+                    if (c0 + 16 * t + 4 * g + r >= p.T || !vq) pr = 0.0f;
+                    ds[u][r] = pr * (dp[r] - delta) * p.scale;
+                }
+            }
+            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                qacc[dt] = mma16<T>(frag_tr<T>(Ks, G::LD, gi * KG, dt * 16, lane), sb, qacc[dt]);
+        }
+    }
+    if (vq) {
+        T* row = (T*)p.dqkv + ((size_t)n * p.T + qrow) * 3 * p.D + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) store4(row + dt * 16, qacc[dt][0], qacc[dt][1], qacc[dt][2], qacc[dt][3]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_long_dkv_kernel(const AttnArgs p, const AttnLongBwd x) {
+    using G = attn::Geo<T>;
+    constexpr int KG = Prec<T>::KG, NG = ATT_LC / KG, TPG = KG / 16;
+    __shared__ __attribute__((aligned(16))) unsigned char Qs[ATT_LC * G::LD];
+    __shared__ __attribute__((aligned(16))) unsigned char Ds[ATT_LC * G::LD];
+    __shared__ __attribute__((aligned(16))) float st_l[ATT_LC];
+    __shared__ __attribute__((aligned(16))) float st_d[ATT_LC];
+    const int bx = blockIdx.x, n = bx / p.H, h = bx % p.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const size_t ldq = (size_t)3 * p.D * sizeof(T), ldo = (size_t)p.D * sizeof(T);
+    const unsigned char* qbase = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
+    const unsigned char* dobase = (const unsigned char*)p.dout + (size_t)n * p.T * ldo + (size_t)h * 64 * sizeof(T);
+    const int krow = blockIdx.y * ATT_LC + 16 * wave + i;
+    const bool vk = krow < p.T;
+    u32x4 kf[G::NKG], vf[G::NKG];
+    attn::load_row_frags<T>(kf, qbase + (size_t)p.D * sizeof(T), ldq, krow, vk, g);
+    attn::load_row_frags<T>(vf, qbase + (size_t)2 * p.D * sizeof(T), ldq, krow, vk, g);
+    const float ck = p.scale * ExpK<T>::K;
+    const uint32_t hbase = (uint32_t)bx * (uint32_t)p.T, T4 = (uint32_t)((p.T + 3) & ~3);
+    const bool dropping = p.drop.thr != 0;
+    f32x4 kacc[4], vacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
+    for (int c0 = 0; c0 < p.T; c0 += ATT_LC) {
+        __syncthreads();
+        attn::load_tile<T>(Qs, qbase + (size_t)c0 * ldq, ldq, p.T - c0, ATT_LC);
+        attn::load_tile<T>(Ds, dobase + (size_t)c0 * ldo, ldo, p.T - c0, ATT_LC);
+        if (threadIdx.x < ATT_LC) {
+            const int q = c0 + threadIdx.x;
+            const size_t sidx = ((size_t)n * p.T + (q < p.T ? q : 0)) * p.H + h;
+            st_l[threadIdx.x] = q < p.T ? p.lse[sidx] * ExpK<T>::K : 0.0f;
+            st_d[threadIdx.x] = q < p.T ? x.delta[sidx] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x4 pd[2], ds[2];
+#pragma unroll
+            for (int u = 0; u < TPG; ++u) {
+                const int t = gi * TPG + u;
+                const f32x4 sa = attn::tile_dot<T>(Qs, t, kf, i, g);     // S[query c0 + 16t + 4g + r][key krow]
+                const f32x4 da = attn::tile_dot<T>(Ds, t, vf, i, g);
+                const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
+                const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = c0 + 16 * t + 4 * g + r;
+                    float pr = ExpK<T>::ex(sa[r] * ck - l4[r]);
+                    if (!(q < p.T && vk)) pr = 0.0f;
+                    float dv = da[r];
+                    pd[u][r] = pr;
+                    if (dropping) {
+                        const bool keep = drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr);
+                        dv = keep ? dv * p.drop.scale : 0.0f;
+                        pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
+                    }
+                    ds[u][r] = pr == 0.0f ? 0.0f : pr * (dv - d4[r]) * p.scale;
+                }
+            }
+            const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);
+            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                vacc[dt] = mma16<T>(frag_tr<T>(Ds, G::LD, gi * KG, dt * 16, lane), pb, vacc[dt]);
+                kacc[dt] = mma16<T>(frag_tr<T>(Qs, G::LD, gi * KG, dt * 16, lane), sb, kacc[dt]);
+            }
+        }
+    }
+    if (vk) {
+        T* row = (T*)p.dqkv + ((size_t)n * p.T + krow) * 3 * p.D + h * 64 + 4 * g;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            store4(row + p.D + dt * 16, kacc[dt][0], kacc[dt][1], kacc[dt][2], kacc[dt][3]);
+            store4(row + 2 * p.D + dt * 16, vacc[dt][0], vacc[dt][1], vacc[dt][2], vacc[dt][3]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Last layer: only frame t = 0 of the encoder output is consumed (reference Modules.py:54), so its
 // attention needs ONE query per (utterance, head).  fp32 vector math (2*T*64 MACs per head), no MFMA:
 // the kernels are pure K/V streaming.  One block = one utterance, wave h = head h, lane = key (scores)
@@ -323,7 +568,8 @@ struct AttnQ0Args {
 };
 
 namespace attn {
-constexpr int Q0_KPL = 5;     // keys per lane -> T <= 320
+constexpr int Q0_KPL = 5;     // keys per lane -> T <= 320 (the trained lengths); Q0_KPL_LONG for T <= 1024
+constexpr int Q0_KPL_LONG = 16;
 template <typename T> __device__ __forceinline__ float dot64_row(const T* row, const float* vec) {
     float acc = 0.0f;
 #pragma unroll
@@ -335,9 +581,8 @@ template <typename T> __device__ __forceinline__ float dot64_row(const T* row, c
 }
 }  // namespace attn
 
-template <typename T, bool BWD>
+template <typename T, bool BWD, int KPL = attn::Q0_KPL>
 __global__ void __launch_bounds__(256) attn_q0_kernel(const AttnQ0Args p) {
-    constexpr int KPL = attn::Q0_KPL;
     __shared__ float qs[4][64], dos[4][64], ps[4][64 * KPL], dss[4][64 * KPL];
     const int n = blockIdx.x, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
     if (h >= p.H) return;                                   // heads <= 4 (emb 256 / 64)

@@ -26,7 +26,8 @@ using namespace ge2e;
 namespace {
 
 constexpr int MAX_LAYERS = 8;
-constexpr int MAX_KT = 9;                 // attention instantiated for T <= 32 * MAX_KT = 288 frames
+constexpr int MAX_KT = 9;                 // sequence-resident attention instantiated for T <= 32 * MAX_KT = 288 frames
+constexpr int MAX_FRAMES = 1024;          // longer sequences stream through the chunked kernels (attention.cuh), up to here
 
 struct ParamInfo { std::string name; int64_t numel, offset; };
 
@@ -103,6 +104,7 @@ struct Layout {
     size_t xt = 0;               // packed mel: [R][KP] of T (row-major copy of the channels-first fp32 input)
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
+    size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
     size_t dP2 = 0, dM2 = 0, c_dP2 = 0, c_dM2 = 0;     // outputs of the norm1 backward (set 2: the side stream still reads set 1)
@@ -162,6 +164,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dP = take(R * d * e); L.dM = take(R * d * e);
         L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
         L.dP2 = take(R * d * e); L.dM2 = take(R * d * e);
+        L.adelta = t > 32 * MAX_KT ? take(R * (size_t)c.heads * 4) : (size_t)-1;
         const size_t nn = (size_t)n;
         L.c_dP2 = take(nn * d * e); L.c_dM2 = take(nn * d * e);
         L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
@@ -397,8 +400,29 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
     }
     return 0;
 }
+// 288 < T <= 1024: K / V (or Q / dO) stream through LDS in 64-row chunks (attention.cuh, "Long sequences")
 template <typename T>
-int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
+int launch_attn_long(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd, float* delta) {
+    const dim3 grid(n * a.H, (a.T + ATT_LC - 1) / ATT_LC), block(256);
+    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H,
+                 (double)n * a.T * a.D * sizeof(T) * (bwd ? 8.0 : 4.0));
+    if (!bwd) {
+        auto kern = attn_fwd_long_kernel<T>;
+        GE2E_LAUNCH(h, kern, grid, block, 0, st, a);
+    } else {
+        if (!delta) return fail(h, GE2E_EINVAL, "long-sequence attention backward needs the delta scratch");
+        AttnLongBwd x{delta};
+        auto k1 = attn_bwd_long_dq_kernel<T>;
+        GE2E_LAUNCH(h, k1, grid, block, 0, st, a, x);
+        auto k2 = attn_bwd_long_dkv_kernel<T>;
+        GE2E_LAUNCH(h, k2, grid, block, 0, st, a, x);
+    }
+    return 0;
+}
+
+template <typename T>
+int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd, float* delta = nullptr) {
+    if (a.T > 32 * MAX_KT) return launch_attn_long<T>(h, st, a, n, bwd, delta);
     const bool pad = a.T % 32 != 0;      // multiples of 32 frames need no key / query masking
     switch ((a.T + 31) / 32) {
         case 1: return pad ? launch_attn_kt<T, 1, true>(h, st, a, n, bwd) : launch_attn_kt<T, 1, false>(h, st, a, n, bwd);
@@ -410,17 +434,22 @@ int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bw
         case 7: return pad ? launch_attn_kt<T, 7, true>(h, st, a, n, bwd) : launch_attn_kt<T, 7, false>(h, st, a, n, bwd);
         case 8: return pad ? launch_attn_kt<T, 8, true>(h, st, a, n, bwd) : launch_attn_kt<T, 8, false>(h, st, a, n, bwd);
         case 9: return pad ? launch_attn_kt<T, 9, true>(h, st, a, n, bwd) : launch_attn_kt<T, 9, false>(h, st, a, n, bwd);
-        default: return fail(h, GE2E_EUNSUPPORTED, "attention: frames > 288 not instantiated");
+        default: return fail(h, GE2E_EUNSUPPORTED, "attention: frame count not instantiated");
     }
 }
 
 template <typename T>
 int launch_attn_q0(ge2e_handle h, hipStream_t st, const AttnQ0Args& a, int n, bool bwd) {
-    if (a.T > 64 * attn::Q0_KPL || a.H > 4) return fail(h, GE2E_EUNSUPPORTED, "q0 attention: frames > 320 or heads > 4");
+    if (a.T > 64 * attn::Q0_KPL_LONG || a.H > 4) return fail(h, GE2E_EUNSUPPORTED, "q0 attention: frames > 1024 or heads > 4");
     ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 10.0 : 4.0) * a.T * 64.0 * n * a.H,
                  (double)n * a.T * a.D * sizeof(T) * (bwd ? 4.0 : 2.0));
-    if (bwd) { auto kern = attn_q0_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
-    else { auto kern = attn_q0_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+    if (a.T <= 64 * attn::Q0_KPL) {
+        if (bwd) { auto kern = attn_q0_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+        else { auto kern = attn_q0_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+    } else {        // up to Max_Position 1024: 16 keys per lane
+        if (bwd) { auto kern = attn_q0_kernel<T, true, attn::Q0_KPL_LONG>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+        else { auto kern = attn_q0_kernel<T, false, attn::Q0_KPL_LONG>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
+    }
     return 0;
 }
 
@@ -444,9 +473,11 @@ int check_common(ge2e_handle h, int n, int t, int samples, const void* ws, size_
     const ge2e_config& c = h->cfg;
     { const int e = check_device(h); if (e) return e; }
     if (n <= 0 || t <= 0 || samples <= 0 || n % samples != 0) return fail(h, GE2E_EINVAL, "n_utts/frames/samples invalid");
-    if (t > 32 * MAX_KT) return fail(h, GE2E_EUNSUPPORTED, "frames > 288 not supported by the attention kernels");
+    if (t > MAX_FRAMES) return fail(h, GE2E_EUNSUPPORTED, "frames > 1024 not supported by the attention kernels");
     if (t > c.max_position) return fail(h, GE2E_EINVAL, "frames > max_position");
     if ((double)n * t * c.ffn >= 4294967296.0) return fail(h, GE2E_EUNSUPPORTED, "n_utts*frames*ffn must stay below 2^32 (dropout counters)");
+    if ((double)n * c.heads * t * ((t + 3) / 4 * 4) >= 4294967296.0)
+        return fail(h, GE2E_EUNSUPPORTED, "n_utts*heads*frames^2 must stay below 2^32 (attention dropout counters)");
     if (!ws || ws_bytes < L.total) return fail(h, GE2E_EWORKSPACE, "workspace too small (see ge2e_workspace_bytes)");
     if (((uintptr_t)ws & 255) != 0) return fail(h, GE2E_EINVAL, "workspace must be 256-byte aligned");
     return 0;
@@ -802,7 +833,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.o = ws + L.o[l]; a.lse = (float*)(ws + L.lse[l]);
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
-            CK(launch_attn<T>(h, st, a, n, true));
+            CK(launch_attn<T>(h, st, a, n, true, L.adelta != (size_t)-1 ? (float*)(ws + L.adelta) : nullptr));
             sc.fork();
             WgradArgs w{};
             w.Y = ws + L.dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
@@ -929,7 +960,7 @@ const char* ge2e_param_name(ge2e_handle h, int i) { return (h && i >= 0 && i < (
 int64_t ge2e_param_numel(ge2e_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].numel : -1; }
 int64_t ge2e_param_offset(ge2e_handle h, int i) { return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].offset : -1; }
 int64_t ge2e_param_total(ge2e_handle h) { return h ? h->total : -1; }
-int ge2e_max_frames(ge2e_handle h) { (void)h; return 32 * MAX_KT; }
+int ge2e_max_frames(ge2e_handle h) { return h ? std::min(MAX_FRAMES, h->cfg.max_position) : MAX_FRAMES; }
 
 size_t ge2e_workspace_bytes(ge2e_handle h, int n_utts, int frames, int train) {
     if (!h || n_utts <= 0 || frames <= 0) return 0;

@@ -73,7 +73,9 @@ def test_workspace_sizes_and_limits():
         assert tr > ev > 0
         assert h16.workspace_bytes(n, t, True) < tr
     assert h32.workspace_bytes(0, 160, True) == 0
-    assert h32.max_frames() == 288
+    assert h32.max_frames() == 1024                      # = Max_Position: whatever reference Modules.py:107-109 accepts
+    assert _lib.Handle(max_position=400).max_frames() == 400
+    assert h32.workspace_bytes(4, 512, True) > h32.workspace_bytes(4, 288, True)
     # config 5 (2560 x 180, bf16 storage) must fit one 288 GB MI355X many times over
     assert h16.workspace_bytes(2560, 180, True) < 32 * 2 ** 30
 

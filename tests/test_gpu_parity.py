@@ -220,6 +220,52 @@ def test_f16_train_step_vs_oracle(mods, n, t, P, p, tag):
         assert cos > 0.999 and rel_l2(g, r) < 5e-2, (name, cos, rel_l2(g, r))
 
 
+@pytest.mark.parametrize("prec,n,t,P", [("fp32", 4, 512, 2), ("fp32", 3, 300, 3), ("bf16", 4, 512, 2), ("fp16", 4, 1024, 2)])
+def test_long_sequences_up_to_max_position(mods, prec, n, t, P):
+    """reference Modules.py:107-109 slices the positional table for any T <= Max_Position (1024).  Beyond 288 frames the
+    attention streams K / V through LDS in chunks (online softmax forward, two chunked backward kernels): a full train step
+    against the oracle, same dropout masks, at T = 512 (8 chunks), 300 (just past the resident kernels, ragged last chunk)
+    and the maximum 1024."""
+    GE2E, GE2E_Loss = mods
+    p = 0.1
+    m, params, pe = build(GE2E, prec, p)
+    m.train()
+    x_np = O.formula_mel(31, n, 80, t, logmel=True)
+    taps = {}
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=p, p_tf=p, taps=taps, pe=pe)
+    loss_ref, lc = O.loss_forward(emb_ref, P)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    emb = m(torch.from_numpy(x_np).cuda())
+    loss = GE2E_Loss().cuda()(emb, P)
+    scale = 1024.0 if prec == "fp16" else 1.0
+    (loss * scale).backward()
+    e = emb.detach().cpu().numpy()
+    o1 = m.workspace_view("o.1", n, t, True).float().cpu().numpy().reshape(n, t, 256)
+    if prec == "fp32":
+        assert rel_l2(o1, taps["o1"]) < 1e-5                           # the chunked attention itself
+        assert np.abs(e - emb_ref).max() < 1e-5 and rel_l2(e, emb_ref) < 1e-4
+        assert abs(loss.item() - float(loss_ref)) < 1e-5
+        tol = 2e-3 if _relu_margin_ok(c) else 0.2
+        for name, prm in m.named_parameters():
+            assert rel_l2(prm.grad.cpu().numpy(), grads_ref[name]) < tol, name
+    else:
+        etol, gtol, ctol = (2e-2, 0.3, 0.97) if prec == "bf16" else (3e-3, 6e-2, 0.998)
+        assert rel_l2(o1, taps["o1"]) < etol and rel_l2(e, emb_ref) < etol
+        for name, prm in m.named_parameters():
+            g, r = (prm.grad.cpu().numpy().ravel() / scale).astype(np.float64), grads_ref[name].ravel().astype(np.float64)
+            if g.size == 1:
+                continue
+            assert np.isfinite(g).all(), name
+            cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            assert cos > ctol and rel_l2(g, r) < gtol, (name, cos, rel_l2(g, r))
+    # eval mode (multi-slice inference shape family) at the same length
+    m.eval()
+    ref, _ = O.encoder_forward(params, x_np, pe=pe)
+    with torch.no_grad():
+        ev = m(torch.from_numpy(x_np).cuda()).cpu().numpy()
+    assert rel_l2(ev, ref) < {"fp32": 1e-4, "bf16": 2e-2, "fp16": 3e-3}[prec]
+
+
 @pytest.mark.parametrize("layers", [1, 2])
 def test_fp32_other_layer_counts(mods, layers):
     """Num_Layers is a hyper-parameter: the frame-0-only treatment of the LAST layer must hold for any depth."""
@@ -304,8 +350,8 @@ def test_full_size_properties(mods, prec, S, P, T):
 def test_error_behaviour(mods):
     GE2E, GE2E_Loss = mods
     m, _, _ = build(GE2E, "fp32", 0.1)
-    with pytest.raises(RuntimeError, match="frames > 288"):
-        m(torch.zeros(2, 80, 300, device="cuda"))
+    with pytest.raises(RuntimeError, match="frames > 1024"):
+        m(torch.zeros(2, 80, 1030, device="cuda"))
     with pytest.raises(RuntimeError, match="Mel_dim"):
         m(torch.zeros(2, 64, 32, device="cuda"))
     with pytest.raises(RuntimeError, match="multiple of samples"):
