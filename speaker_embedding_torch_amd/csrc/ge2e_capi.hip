@@ -18,6 +18,7 @@
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
 #include "ffn.cuh"
+#include "wgrad_ks.cuh"
 #include "misc.cuh"
 #include "melfront.cuh"
 
@@ -27,6 +28,7 @@ namespace {
 
 constexpr int MAX_LAYERS = 8;
 constexpr int MAX_KT = 9;                 // sequence-resident attention instantiated for T <= 32 * MAX_KT = 288 frames
+constexpr int WK_MAX_BLOCKS = 256;        // blocks (= partial tiles) of one wgrad_ks launch: one per CU
 constexpr int MAX_FRAMES = 1024;          // longer sequences stream through the chunked kernels (attention.cuh), up to here
 
 struct ParamInfo { std::string name; int64_t numel, offset; };
@@ -105,6 +107,7 @@ struct Layout {
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
+    size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
     size_t dP2 = 0, dM2 = 0, c_dP2 = 0, c_dM2 = 0;     // outputs of the norm1 backward (set 2: the side stream still reads set 1)
@@ -165,6 +168,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
         L.dP2 = take(R * d * e); L.dM2 = take(R * d * e);
         L.adelta = t > 32 * MAX_KT ? take(R * (size_t)c.heads * 4) : (size_t)-1;
+        L.wpart = e == 2 ? take((size_t)WK_MAX_BLOCKS * WK_TILE_FLOATS * 4) : (size_t)-1;
         const size_t nn = (size_t)n;
         L.c_dP2 = take(nn * d * e); L.c_dM2 = take(nn * d * e);
         L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
@@ -349,8 +353,49 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
     }
 }
 
+// 256 x 256-tile split-K weight gradient (wgrad_ks.cuh) for the wide 16-bit products; everything else (and the rows beyond the
+// last multiple of 32) on the 128 x 128 kernel below.
+inline bool wgrad_ks_on() { static const bool off = getenv("GE2E_NO_WGRAD_KS") != nullptr; return !off; }
+template <typename T, int XLOAD> int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a);
+
 template <typename T, int XLOAD>
-int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a) {
+int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullptr) {
+    if constexpr (sizeof(T) == 2) {
+        const int tn = a.N / 256, tk = a.K / 256;
+        if (part && wgrad_ks_on() && a.N % 256 == 0 && a.K % 256 == 0 && tn * tk >= 2 && tn * tk <= 16 && a.R >= 256 &&
+            a.ldy % 8 == 0 && a.ldx % 8 == 0) {
+            if (h->num_cus <= 0) {
+                int n = 0;
+                if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device >= 0 ? h->device : 0) != hipSuccess || n <= 0) n = 256;
+                h->num_cus = n;
+            }
+            const int R32 = a.R / 32 * 32, stages = R32 / 32;
+            int splits = std::min(WK_MAX_BLOCKS, h->num_cus) / (tn * tk);
+            splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
+            const int sps = (stages + splits - 1) / splits;
+            splits = (stages + sps - 1) / sps;
+            WgradKsArgs k{};
+            k.Y = a.Y; k.ldy = a.ldy; k.X = a.X; k.ldx = a.ldx; k.part = part; k.db = a.db; k.R32 = R32; k.rows_per_split = sps * 32;
+            k.tiles_n = tn; k.tiles_k = tk;
+            {
+                ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R32 * (double)a.N * a.K, (double)R32 * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
+                auto kern = wgrad_ks_kernel<T>;
+                GE2E_LAUNCH(h, kern, dim3(tn * tk * splits), dim3(512), wgrad_ks_smem(), st, k);
+            }
+            GE2E_LAUNCH(h, wgrad_ks_reduce_kernel, dim3(tn * tk * 64), dim3(256), 0, st, (const float*)part, a.dW, a.ldw, splits, tn, tk);
+            if (R32 == a.R) return 0;
+            WgradArgs tail = a;                                          // < 32 rows left: the tiled kernel adds them atomically
+            tail.Y = (const unsigned char*)a.Y + (size_t)R32 * a.ldy * sizeof(T);
+            tail.X = (const unsigned char*)a.X + (size_t)R32 * a.ldx * sizeof(T);
+            tail.R = a.R - R32;
+            return launch_wgrad_tiled<T, XLOAD>(h, st, tail);
+        }
+    }
+    return launch_wgrad_tiled<T, XLOAD>(h, st, a);
+}
+
+template <typename T, int XLOAD>
+int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a) {
     constexpr int RS = 2 * Prec<T>::KG;
     constexpr int LD = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     if (a.N % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: N must be a multiple of 128");
@@ -716,6 +761,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
     if (e != hipSuccess) return fail_hip(h, e, "zero grads");
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
+    float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
     hipEvent_t g_set1 = nullptr, g_set2 = nullptr, g_dF = nullptr, g_dQKV = nullptr;   // last side-stream reader of a buffer
     {
         TailArgs a{};
@@ -777,14 +823,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
             g_set1 = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
             a.R = Rl; a.N = c.ffn; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
             g_dF = sc.mark();
         }
         {   // dH1 = dPre2 + dF W1
@@ -823,7 +869,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
             a.R = Rl; a.N = d; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
             g_set2 = sc.mark();
         }
         sc.wait(g_dQKV);
@@ -838,7 +884,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs w{};
             w.Y = ws + L.dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
             w.R = R; w.N = 3 * d; w.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
             g_dQKV = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
             g.A = ws + L.dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
@@ -855,7 +901,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             wkv.Y = ws + L.dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
             wkv.dW = G(lp(l, L_IN_W)) + (size_t)d * d; wkv.ldw = d; wkv.db = G(lp(l, L_IN_B)) + d;
             wkv.R = R; wkv.N = 2 * d; wkv.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wkv)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wkv, wpart)));
             WgradArgs wq{};   // q rows from frame 0 of every utterance
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
@@ -885,7 +931,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
         w.Y = ws + L.dHa; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
-        CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w)));
+        CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
     }
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again
