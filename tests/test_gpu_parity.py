@@ -7,8 +7,8 @@ Tolerances (north_star: d-vectors within 1e-4 of the CPU reference on the fp32 p
   fp32 path : d-vector max-abs <= 1e-5 and vector-relative <= 1e-4 (observed ~1e-6);
               gradients per tensor relative L2 <= 2e-3 (observed ~1e-4; fp32 atomics order varies)
   bf16 path : storage is bf16 (8 mantissa bits) -> d-vector max-abs <= 6e-3 on unit-norm vectors,
-              relative L2 <= 2e-2; gradients: cosine >= 0.98 per tensor and relative L2 <= 0.25
-              (ReLU masks flip where a pre-activation is within bf16 rounding of zero).
+              relative L2 <= 2e-2; gradients: cosine >= 0.99 per tensor and relative L2 <= 0.15 (observed 0.094 worst + 50 %;
+              ReLU masks flip where a pre-activation is within bf16 rounding of zero).
   fp16 path : storage is IEEE half (11 mantissa bits) -> 8x tighter than bf16: d-vector relative L2 <= 3e-3,
               gradients (taken under a loss scale, as the reference's GradScaler does) cosine >= 0.999, relative L2 <= 5e-2.
   16-bit kernels, one by one: tests/test_gpu_kernels_16bit.py checks every kernel of the bf16 / fp16 path against an
@@ -187,7 +187,10 @@ def test_bf16_train_step_vs_oracle(mods, n, t, P, p, tag):
             assert abs(g[0] - r[0]) < 0.15 * np.linalg.norm(grads_ref["prenet.bias"]), name
             continue
         cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
-        assert cos > 0.98 and rel_l2(g, r) < 0.25, (name, cos)
+        # observed on the MI355X over the three cases: worst relative L2 0.094 (prenet.bias), lowest cosine 0.9957 -> bound = that + 50 %.
+        # (Each bf16 kernel on its own is exact to a rounding: tests/test_gpu_kernels_16bit.py; profiles/r02_precision_taps.md
+        # shows where the storage rounding accrues.)
+        assert cos > 0.99 and rel_l2(g, r) < 0.15, (name, cos, rel_l2(g, r))
 
 
 @pytest.mark.parametrize("n,t,P,p,tag", CASES[:3])

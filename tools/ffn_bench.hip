@@ -49,6 +49,14 @@ int main(int argc, char** argv) {
     run<false, 0>("eval  full, 200 blocks", a, 200);
     run<true, 0>("train full (dropout on, hidden stored)", ad, 256);
     run<true, 0>("train full, 200 blocks", ad, 200);
+    run<true, 0>("train, dropout off (thr = 0), hidden stored", a, 256);
+    { FfnArgs an = ad; run<false, 0>("dropout on, hidden NOT stored (eval kernel)", an, 256); }
+    run<true, 1>("train no MFMA", ad, 256);
+    run<true, 2>("train no DMA", ad, 256);
+    run<true, 8>("train no barrier", ad, 256);
+    run<true, 16>("train no hidden epilogue math", ad, 256);
+    run<true, 64>("train no pass epilogue", ad, 256);
+    run<true, 32>("train no stage loop", ad, 256);
     run<false, 1>("eval  no MFMA", a, 256);
     run<false, 2>("eval  no DMA", a, 256);
     run<false, 4>("eval  no fragment reads", a, 256);

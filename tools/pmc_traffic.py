@@ -14,7 +14,9 @@ from collections import defaultdict
 CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
     "gemm": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_ws_lnbwd_kernel" in n) and not is_ln(n),
     "gemm_ln": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_kl_kernel" in n) and is_ln(n),
-    "wgrad": lambda n: "wgrad_kernel" in n,
+    "wgrad": lambda n: "wgrad_kernel" in n or "wgrad_ks_kernel" in n,          # what bench.py's wgrad class brackets (not the reduce pass)
+    "wgrad_reduce": lambda n: "wgrad_ks_reduce_kernel" in n,
+    "ffn": lambda n: "ffn_chain_kernel" in n,
     "attn_fwd": lambda n: "attn_fwd_kernel" in n,
     "attn_bwd": lambda n: "attn_bwd_kernel" in n,
 }
@@ -22,8 +24,10 @@ CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
 
 def is_ln(n):
     # EPI_LN == 3: gemm_nt_kernel<T,64,256,32,128,3,...>, gemm_ws_kernel<3,256>, gemm_kl_kernel<3,...>
+    # (round 2: the streaming kernels are templated on the storage type first: gemm_ws_kernelIDF16bLi3E... / IDF16_Li3E...)
     return ("Li64ELi256ELi32ELi128ELi3E" in n or "gemm_ws_kernelILi3E" in n or "gemm_ws_kernel<3," in n
-            or "gemm_kl_kernelILi3E" in n or "gemm_kl_kernel<3," in n)
+            or "gemm_kl_kernelILi3E" in n or "gemm_kl_kernel<3," in n
+            or "gemm_ws_kernelIDF16bLi3E" in n or "gemm_ws_kernelIDF16_Li3E" in n or "gemm_kl_kernelIDF16" in n)
 
 
 def read_pass(d, counter):
