@@ -91,10 +91,12 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         if constexpr ((ABL & 2) == 0) {
         const unsigned char* const s1 = W1g + (size_t)i_c * (32 * 512);       // wave-uniform: hidden units 32 i_c ..
         const unsigned char* const s2 = W2g + (size_t)i_c * 64;
-        glds16(s1 + dma1, slot + (2 * wave) * 1024);                                   // rows 4w, 4w + 1 (512 B each)
-        glds16(s1 + ((dma1 ^ 32u) + 1024u), slot + (2 * wave + 1) * 1024);             // rows 4w + 2, 4w + 3
-        glds16(s2 + dma2, slot + 16384 + (2 * wave) * 1024);                           // 16 rows x 64 B
-        glds16(s2 + 16 * (FFN_F * 2) + dma2, slot + 16384 + (2 * wave + 1) * 1024);    // the next 16 rows
+        unsigned d1 = dma1, d2 = dma2;               // opaque 32-bit copies: the offsets stay ONE register each (not hoisted 64-bit pairs)
+        asm volatile("" : "+v"(d1), "+v"(d2));
+        glds16(s1 + d1, slot + (2 * wave) * 1024);                                     // rows 4w, 4w + 1 (512 B each)
+        glds16(s1 + ((d1 ^ 32u) + 1024u), slot + (2 * wave + 1) * 1024);               // rows 4w + 2, 4w + 3
+        glds16(s2 + d2, slot + 16384 + (2 * wave) * 1024);                             // 16 rows x 64 B
+        glds16(s2 + 16 * (FFN_F * 2) + d2, slot + 16384 + (2 * wave + 1) * 1024);      // the next 16 rows
         }
         if (++i_c == NCH) i_c = 0;
         if (++i_slot == NSTG) i_slot = 0;
@@ -116,6 +118,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     // W2 row r = 8 (i >> 2) + 4 hh + (i & 3) of a 16-row DMA piece sits at chunk position g ^ ((r >> 2) & 3) = g ^ (2 ((i >> 2) & 1) + hh):
     // hh = 1 is hh = 0 with chunk bit 0 flipped (^ 16 B) and 4 rows (256 B) further
     const unsigned w2c = (unsigned)(16384 + w1row * 64 + ((g ^ (2 * ((i >> 2) & 1))) << 4));
+    const int w1q = i >> 2;
 
     auto mm = [&](const u32x4& w, const u32x4& a, f32x4 acc) -> f32x4 {
         if constexpr (ABL & 1) { asm volatile("" :: "v"(w), "v"(a)); return acc; }
@@ -149,7 +152,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     auto stage_bases = [&](int slot_index, unsigned* a1, unsigned* a2) {
         const unsigned so = (unsigned)slot_index * FFN_SLOT;
 #pragma unroll
-        for (int kq = 0; kq < 4; ++kq) { a1[kq] = w1c + so + (unsigned)((kq ^ (i >> 2)) << 6); asm volatile("" : "+v"(a1[kq])); }
+        for (int kq = 0; kq < 4; ++kq) { a1[kq] = w1c + so + (unsigned)((kq ^ w1q) << 6); asm volatile("" : "+v"(a1[kq])); }
         a2[0] = w2c + so; a2[1] = ((w2c ^ 16u) + 256u) + so;
         asm volatile("" : "+v"(a2[0]), "+v"(a2[1]));
     };
@@ -157,12 +160,18 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 #pragma unroll 1
     for (int ps = 0; ps < my; ++ps) {
         const int m0 = (b + ps * G) * 256 + 32 * wave;
+        // Lane-derived values are re-derived from an OPAQUE copy of the lane id wherever they are needed outside the MFMA loops:
+        // otherwise the compiler hoists dozens of loop-invariant addresses / indices out of the pass loop and has to spill them
+        // around the stage loop (every reload is a scratch round trip behind s_waitcnt vmcnt(0), which also drains the DMA ring)
+        auto lane_ids = [&](int& li, int& lg) { int ln = lane; asm volatile("" : "+v"(ln)); li = ln & 15; lg = ln >> 4; };
+        int pi, pg;
+        lane_ids(pi, pg);
         // ---- this wave's 32 rows of h1 as operand fragments: af[rt][kg] = h1[row][32 kg + 8g .. + 7]
         u32x4 af[2][8];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
-            int gr = m0 + 16 * rt + i; gr = gr < last_row ? gr : last_row;
-            const unsigned char* arow = Ag + (size_t)gr * p.lda * 2 + g * 16;
+            int gr = m0 + 16 * rt + pi; gr = gr < last_row ? gr : last_row;
+            const unsigned char* arow = Ag + (size_t)gr * p.lda * 2 + pg * 16;
             asm volatile("" : "+v"(arow));
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) af[rt][kg] = *(const u32x4*)(arow + kg * 64);
@@ -218,6 +227,8 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         };
         // bias + ReLU + dropout in registers; the packed tiles are the hidden's storage-type values (and product 2's operand)
         auto hidden_epilogue = [&](f32x4 (&h)[2][2], u32x4* hp, int c) {
+            int i, g;                                  // shadow the kernel-scope lane ids: re-derived here (see lane_ids)
+            lane_ids(i, g);
             unsigned bb = (unsigned)(NSTG * FFN_SLOT) + (unsigned)(c * 128 + 32 * g);      // &B1s[32 c + 8 g], opaque: constants stay in the offset field
             asm volatile("" : "+v"(bb));
 #pragma unroll
@@ -233,7 +244,11 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
                 }
                 hp[rt] = pack_acc<T>(h[rt][0], h[rt][1]);      // 8 consecutive hidden units 32c + 8g .. + 7 of row (rt, i)
                 if constexpr (STORE_F) {
-                    if (row < p.M) __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + ((size_t)row * p.ldf + c * 32 + 8 * g) * 2));
+                    if (row < p.M) {       // 32-bit offset in 16-byte units (rows x F x 2 B stays below 2^36 B for every shape the library accepts)
+                        unsigned fo = (unsigned)row * (unsigned)(p.ldf >> 3) + (unsigned)(4 * c + g);
+                        asm volatile("" : "+v"(fo));
+                        __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + (size_t)fo * 16));
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -319,17 +334,30 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         // other three quarters sit on the lanes with the same i); rows leave as 16-byte pieces per lane (64 B per row and kg)
         // (addresses: ONE lane-dependent base per table / row, made opaque inside the pass loop -- otherwise the compiler hoists
         // ~100 separately materialised addresses out of the pass loop and spills them around the stage loop)
-        unsigned lb = (unsigned)(NSTG * FFN_SLOT + FFN_F * 4) + (unsigned)(32 * g);          // &Ls[8 g]
+        int ei, eg;
+        lane_ids(ei, eg);
+        unsigned lb = (unsigned)(NSTG * FFN_SLOT + FFN_F * 4) + (unsigned)(32 * eg);         // &Ls[8 g]
         asm volatile("" : "+v"(lb));
 #pragma unroll
         for (int rt = 0; rt < ((ABL & 64) ? 0 : 2); ++rt) {
+            const int i = ei, g = eg;                  // (shadow the kernel-scope lane ids)
             const int row = m0 + 16 * rt + i;
             unsigned char* crow = (unsigned char*)Cg + ((size_t)row * p.ldc + 8 * g) * 2;
             asm volatile("" : "+v"(crow));
             float sm = 0.0f;
+            // residual: the same h1 values the operand fragments held, RE-READ (L2 / Infinity-Cache resident: this block read them
+            // one pass ago) instead of kept: the 64 fragment registers die with the last product 1 and the epilogue runs without
+            // spills (kept alive for the residual they cost ~16 spilled registers around the stage loop, each reload an exposed
+            // scratch round trip behind s_waitcnt vmcnt(0): pass epilogue 18 -> see DESIGN.md)
+            int grr = row < last_row ? row : last_row;
+            const unsigned char* rrow = Ag + (size_t)grr * p.lda * 2 + g * 16;
+            asm volatile("" : "+v"(rrow));
+            u32x4 rres[8];
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) rres[kg] = *(const u32x4*)(rrow + kg * 64);
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) {
-                const T* const res = (const T*)&af[rt][kg];
+                const T* const res = (const T*)&rres[kg];
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     const int col = 32 * kg + 8 * g + 4 * hh;
