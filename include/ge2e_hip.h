@@ -179,8 +179,9 @@ int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_
                       int64_t* launches);
 
 /* Diagnostics: byte offset/size inside the workspace of a named intermediate of the last forward
- * ("h0", "qkv.<l>", "o.<l>", "h1.<l>", "f.<l>", "h2.<l>", and after a backward the scratch of the LAST
- * processed FULL layer: "dF", "dHb", "dP1", "dM1" (norm2 backward), "dP", "dM" (norm1 backward), "dO", "dQKV", "dHa";
+ * ("h0", "qkv.<l>", "o.<l>", "h1.<l>", "f.<l>", "h2.<l>", and after a backward the scratch of FULL layer l: "dF.<l>",
+ * "dP1.<l>", "dM1.<l>" (norm2 backward), "dP.<l>", "dM.<l>" (norm1 backward), "dQKV.<l>" -- layers alternate between buffer
+ * sets, so a layer's scratch survives the next layer's backward -- and of the last processed layer "dHb", "dO", "dHa";
  * element type follows cfg.precision -- except "rstd1.<l>", "rstd2.<l>" and "lse.<l>", which are fp32; "xt" = the packed mel rows).
  * The LAST layer is evaluated for frame 0 only (nothing else of it is consumed, Modules.py:54), so its
  * "o", "h1", "f", "h2" taps are compact [n_utts, width] and its "qkv" holds q in frame-0 rows only.

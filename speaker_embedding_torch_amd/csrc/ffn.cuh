@@ -42,22 +42,29 @@ struct FfnArgs {
     int M;
 };
 
-constexpr int FFN_NSTG = 4;        // ring slots
-constexpr int FFN_D = 3;           // stages in flight ahead of the one being consumed
 constexpr int FFN_SLOT = 32 * 1024;
 constexpr int FFN_F = 1024;        // hidden width (4 x 256)
-constexpr size_t ffn_smem() { return (size_t)FFN_NSTG * FFN_SLOT + (FFN_F + 3 * 256) * 4; }
+// Two block shapes:
+//   WV = 8: one 512-thread block per CU, 256 rows per pass, 4-slot ring three stages ahead, the barrier between the two products
+//           of a stage (it publishes the NEXT stage, whose first fragments are prefetched under this stage's last MFMAs);
+//   WV = 4: TWO independent 256-thread blocks per CU, 128 rows per pass each, a 2-slot ring one stage ahead with the barrier at the
+//           top of the stage.  The two waves of a SIMD then belong to different blocks: no barrier couples them, so one block's
+//           vector-ALU phases, pass prologue (h1 loads) and pass epilogue (LayerNorm, stores) run under the other's MFMAs.  The
+//           weights stream twice per CU (2 x 32 KB per stage time: still under half of the CU's L2 ingest rate).
+template <int WV> constexpr int ffn_nstg() { return WV == 8 ? 4 : 2; }
+template <int WV> constexpr size_t ffn_smem() { return (size_t)ffn_nstg<WV>() * FFN_SLOT + (FFN_F + 3 * 256) * 4; }
 
 // grid = persistent blocks of 512 threads, one per CU at most, sized so that every block runs the same number of passes
 // ABL (development only, tools/ffn_bench.hip): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no barrier, 16 no hidden epilogue
 // STAGGER: waves 4-7 lag by one product (see the stage loop).  Measured at 153,600 rows: train (dropout hashes + hidden store in the
 // hidden epilogue) 310 -> 279 us with it, eval (a light epilogue) 215 -> 243 us: the launcher staggers train mode only.
-template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F>
-__global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const int npass) {
+template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F, int WV = 8>
+__global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(const FfnArgs p, const int npass) {
     static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
+    static_assert(WV == 8 || WV == 4, "waves per block");
     constexpr int NCH = FFN_F / 32;              // stages per pass
-    constexpr int D = FFN_D, NSTG = FFN_NSTG;
-    constexpr int NDMA = 4;                      // DMA instructions per wave and stage
+    constexpr int NSTG = ffn_nstg<WV>(), D = NSTG - 1;
+    constexpr int NDMA = 32 / WV;                // DMA instructions per wave and stage
     constexpr int NST = STORE_F ? 2 : 0;         // hidden-store instructions per wave and stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Ring = smem;                                      // [NSTG][32 KB]: W1 slice | W2 slice
@@ -67,12 +74,12 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const bool lag = STAGGER && wave >= 4;       // wave-uniform (wave comes from readfirstlane)
+    const bool lag = STAGGER && WV == 8 && wave >= 4;       // wave-uniform (wave comes from readfirstlane)
     const int G = gridDim.x, b = blockIdx.x;
     const int my = b < npass ? (npass - b + G - 1) / G : 0;
     if (my == 0) return;
 
-    for (int q = tid; q < FFN_F; q += 512) B1s[q] = p.b1[q];
+    for (int q = tid; q < FFN_F; q += 64 * WV) B1s[q] = p.b1[q];
     if (tid < 256) { Ls[tid] = p.b2[tid]; Ls[256 + tid] = p.gamma[tid]; Ls[512 + tid] = p.beta[tid]; }
     __syncthreads();                              // no DMA in flight yet: an ordinary barrier
 
@@ -82,9 +89,11 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
     // per-lane source offsets (32-bit, loop-invariant) on top of wave-uniform bases.  One VGPR per table: the second
     // instruction of a wave covers W1 rows + 2 (same swizzle with bit 1 of the row flipped: chunk ^ 2, + 1024 B) and W2 rows + 16
     // (same swizzle: a wave-uniform + 16 rows).
-    const int dr1 = 4 * wave + (lane >> 5);
+    // WV = 8: wave w carries W1 pieces 2w, 2w + 1 and W2 pieces 2w, 2w + 1.  WV = 4: waves 0, 1 carry the 16 W1 pieces (8 each),
+    // waves 2, 3 the 16 W2 pieces; piece u of a wave is the first one + a wave-uniform step, the swizzle bit pattern follows the row.
+    const int dr1 = (WV == 8 ? 4 * wave : 16 * (wave & 1)) + (lane >> 5);
     const unsigned dma1 = (unsigned)(dr1 * 512 + (((lane & 31) ^ (((dr1 >> 3) << 2) | (dr1 & 3))) << 4));    // W1 slice row dr1, swizzled chunk (= the lane index i that reads it)
-    const unsigned dma2 = (unsigned)((32 * wave + (lane >> 2)) * (FFN_F * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));   // W2 row 32 w + r2, chunk pos ^ ((r2 >> 2) & 3)
+    const unsigned dma2 = (unsigned)(((WV == 8 ? 32 * wave : 128 * (wave & 1)) + (lane >> 2)) * (FFN_F * 2) + (((lane & 3) ^ ((lane >> 4) & 3)) << 4));   // W2 row, chunk pos ^ ((r2 >> 2) & 3)
     int i_c = 0, i_slot = 0;
     auto issue = [&]() {
         unsigned char* const slot = Ring + i_slot * FFN_SLOT;
@@ -93,10 +102,22 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         const unsigned char* const s2 = W2g + (size_t)i_c * 64;
         unsigned d1 = dma1, d2 = dma2;               // opaque 32-bit copies: the offsets stay ONE register each (not hoisted 64-bit pairs)
         asm volatile("" : "+v"(d1), "+v"(d2));
-        glds16(s1 + d1, slot + (2 * wave) * 1024);                                     // rows 4w, 4w + 1 (512 B each)
-        glds16(s1 + ((d1 ^ 32u) + 1024u), slot + (2 * wave + 1) * 1024);               // rows 4w + 2, 4w + 3
-        glds16(s2 + d2, slot + 16384 + (2 * wave) * 1024);                             // 16 rows x 64 B
-        glds16(s2 + 16 * (FFN_F * 2) + d2, slot + 16384 + (2 * wave + 1) * 1024);      // the next 16 rows
+        if constexpr (WV == 8) {
+            glds16(s1 + d1, slot + (2 * wave) * 1024);                                     // rows 4w, 4w + 1 (512 B each)
+            glds16(s1 + ((d1 ^ 32u) + 1024u), slot + (2 * wave + 1) * 1024);               // rows 4w + 2, 4w + 3
+            glds16(s2 + d2, slot + 16384 + (2 * wave) * 1024);                             // 16 rows x 64 B
+            glds16(s2 + 16 * (FFN_F * 2) + d2, slot + 16384 + (2 * wave + 1) * 1024);      // the next 16 rows
+        } else if (wave < 2) {
+            // W1 rows 16 w + 2 u + (lane >> 5), u = 0..7: the swizzle ((r >> 3) << 2) | (r & 3) of row r0 + 2u differs from r0's in
+            // bit 1 (u odd: chunk ^ 2) and in bit 2 (u >= 4: chunk ^ 4)
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                glds16(s1 + ((d1 ^ (unsigned)((((u & 1) << 1) | ((u >> 2) << 2)) << 4)) + (unsigned)(u * 1024)), slot + (8 * wave + u) * 1024);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u)              // W2 rows 128 (w - 2) + 16 u + (lane >> 2): the swizzle depends on the row inside the piece only
+                glds16(s2 + (size_t)u * (16 * FFN_F * 2) + d2, slot + 16384 + (8 * (wave - 2) + u) * 1024);
+        }
         }
         if (++i_c == NCH) i_c = 0;
         if (++i_slot == NSTG) i_slot = 0;
@@ -159,7 +180,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
 
 #pragma unroll 1
     for (int ps = 0; ps < my; ++ps) {
-        const int m0 = (b + ps * G) * 256 + 32 * wave;
+        const int m0 = (b + ps * G) * (32 * WV) + 32 * wave;
         // Lane-derived values are re-derived from an OPAQUE copy of the lane id wherever they are needed outside the MFMA loops:
         // otherwise the compiler hoists dozens of loop-invariant addresses / indices out of the pass loop and has to spill them
         // around the stage loop (every reload is a scratch round trip behind s_waitcnt vmcnt(0), which also drains the DMA ring)
@@ -204,8 +225,10 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         // between the barrier that published it and the barrier before its refill.
         u32x4 wA[2], wB[2];
         unsigned a1[4], a2[2];
-        stage_bases(c_slot, a1, a2);
-        read_w1(a1, 0, wA);
+        if constexpr (WV == 8) {
+            stage_bases(c_slot, a1, a2);
+            read_w1(a1, 0, wA);
+        }
 
         // product 1 of the stage with bases (b1, b2); ends with the first W2 fragments of the same stage in wA
         auto prod1 = [&](f32x4 (&h)[2][2], const unsigned* b1, const unsigned* b2) {
@@ -260,7 +283,7 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
                 u32x4* const cur = (q & 1) ? wB : wA;
                 u32x4* const nxt = (q & 1) ? wA : wB;
                 if (q < 7) read_w2(b2, q + 1, nxt);
-                else read_w1(nb1, 0, nxt);           // q == 7: nxt == wA
+                else if constexpr (WV == 8) read_w1(nb1, 0, nxt);           // q == 7: nxt == wA (WV = 4: the next stage is not published yet)
 #pragma unroll
                 for (int hh = 0; hh < 2; ++hh) {
                     oacc[0][2 * q + hh] = mm(cur[hh], hp[0], oacc[0][2 * q + hh]);
@@ -273,8 +296,11 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
         // stage c + 1 must be complete before anyone reads from it, and the slot of stage c - 1 is refilled: this wave's pieces
         // of stage c + 1 have landed once at most the (D-2) younger stages' DMAs and the (D-1) stages' worth of hidden stores
         // issued since are outstanding
+        // (WV = 4, D = 1: the barrier sits at the top of stage c and publishes stage c itself, whose DMAs are older than the previous
+        // stage's hidden stores only; the refill that follows goes to the slot of stage c - 1)
+        constexpr int PUBW = WV == 8 ? (D - 2) * NDMA + (D - 1) * NST : NST;
         auto publish_next = [&]() {
-            wait_vmcnt<(D - 2) * NDMA + (D - 1) * NST>();
+            wait_vmcnt<PUBW>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +308,20 @@ __global__ void __launch_bounds__(512) ffn_chain_kernel(const FfnArgs p, const i
             __builtin_amdgcn_sched_barrier(0);
         };
         constexpr int NCHR = (ABL & 32) ? 0 : NCH;
-        if (!lag) {
+        if constexpr (WV == 4) {
+#pragma unroll 1
+            for (int c = 0; c < NCHR; ++c) {
+                f32x4 h[2][2];
+                u32x4 hp[2];
+                if (c > 0) publish_next();             // stage 0 was published by the pass-start barrier
+                else { issue(); __builtin_amdgcn_sched_barrier(0); }
+                stage_bases(c & 1, a1, a2);            // NCH is even: stage c of every pass sits in slot c & 1
+                read_w1(a1, 0, wA);
+                prod1(h, a1, a2);
+                hidden_epilogue(h, hp, c);
+                prod2(hp, a2, a1);
+            }
+        } else if (!lag) {
 #pragma unroll 1
             for (int c = 0; c < NCHR; ++c) {
                 f32x4 h[2][2];

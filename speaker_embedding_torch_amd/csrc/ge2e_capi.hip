@@ -110,8 +110,14 @@ struct Layout {
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
     size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
-    size_t dHa = 0, dHb = 0, dP = 0, dM = 0, dF = 0, dQKV = 0, dO = 0;
-    size_t dP2 = 0, dM2 = 0, c_dP2 = 0, c_dM2 = 0;     // outputs of the norm1 backward (set 2: the side stream still reads set 1)
+    size_t dHa = 0, dHb = 0, dO = 0;
+    // Scratch the side stream's weight-gradient kernels read after the main chain has moved on: norm2-backward outputs (dP, dM),
+    // norm1-backward outputs (dP2, dM2), dF and dQKV.  Layer l uses set l % nset (dQKV: l % nqkv), so with up to 3 layers the main
+    // chain never writes a buffer a weight gradient of the same backward may still be reading -- no main-stream wait (each is a
+    // barrier packet: ~6 us of idle queue even when already satisfied); deeper stacks wait for the reader two (three) layers up.
+    int nset = 1, nqkv = 1;
+    size_t dP[2] = {0, 0}, dM[2] = {0, 0}, dF[2] = {0, 0}, dQKV[3] = {0, 0, 0};
+    size_t dP2[2] = {0, 0}, dM2[2] = {0, 0}, c_dP2 = 0, c_dM2 = 0;
     // last layer: only frame 0 of its output is consumed, so everything after its K/V projection lives on
     // COMPACT rows (one per utterance): o/h1/f/h2 of that layer and this backward scratch
     size_t c_dH = 0, c_dHb = 0, c_dP = 0, c_dM = 0, c_dF = 0, c_dO = 0, c_dQ0 = 0, c_tmp = 0;
@@ -165,9 +171,14 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     L.zm = take((size_t)n * d * 4);     L.nrm = take((size_t)n * 4);
     L.emb_keep = take((size_t)n * d * 4); L.d_raw = take((size_t)n * d * 4);
     if (train) {
-        L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dP = take(R * d * e); L.dM = take(R * d * e);
-        L.dF = take(R * f * e);  L.dQKV = take(R * 3 * d * e); L.dO = take(R * d * e);
-        L.dP2 = take(R * d * e); L.dM2 = take(R * d * e);
+        L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dO = take(R * d * e);
+        L.nset = c.layers >= 3 ? 2 : 1;              // full-size layers are 0 .. layers - 2 (the last one runs on compact rows)
+        L.nqkv = std::min(c.layers, 3);              // dQKV is full-size in every layer
+        for (int s = 0; s < L.nset; ++s) {
+            L.dP[s] = take(R * d * e); L.dM[s] = take(R * d * e); L.dF[s] = take(R * f * e);
+            L.dP2[s] = take(R * d * e); L.dM2[s] = take(R * d * e);
+        }
+        for (int s = 0; s < L.nqkv; ++s) L.dQKV[s] = take(R * 3 * d * e);
         L.adelta = t > 32 * MAX_KT ? take(R * (size_t)c.heads * 4) : (size_t)-1;
         L.wpart = e == 2 ? take((size_t)WK_MAX_BLOCKS * WK_TILE_FLOATS * 4) : (size_t)-1;
         const size_t nn = (size_t)n;
@@ -335,21 +346,31 @@ template <typename T>
 int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
     if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "ffn chain: 16-bit modes only");
     else {
-        const int npass = (a.M + 255) / 256;
         if (h->num_cus <= 0) {
             int n = 0;
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device >= 0 ? h->device : 0) != hipSuccess || n <= 0) n = 256;
             h->num_cus = n;
         }
-        // every block runs ceil(npass / CUs) passes: a grid of ceil(npass / that) blocks finishes at the same time as one block
-        // per CU would, with fewer blocks competing for the weight stream (600 passes: 200 blocks x 3 measured 189 us, 256 blocks 215 us)
-        const int per_block = (npass + h->num_cus - 1) / h->num_cus;
-        const int grid = (npass + per_block - 1) / per_block;
+        // block shape (ffn.cuh): two 4-wave blocks per CU by default (alone: eval 172 vs 191 us, train 224 vs 230 us; the bf16 training
+        // step 4.09 vs 4.12 ms); GE2E_FFN_WV=8 selects the one-block-per-CU shape
+        static const int wv = getenv("GE2E_FFN_WV") && atoi(getenv("GE2E_FFN_WV")) == 8 ? 8 : 4;
+        const int rows_pass = wv == 4 ? 128 : 256, slots = wv == 4 ? 2 * h->num_cus : h->num_cus;
+        const int npass = (a.M + rows_pass - 1) / rows_pass;
+        // every block runs ceil(npass / slots) passes: a grid of ceil(npass / that) blocks finishes at the same time as a full
+        // grid would, with fewer blocks competing for the weight stream (600 passes: 200 blocks x 3 measured 189 us, 256 blocks 215 us)
+        // (4-wave blocks: a full grid; the blocks with one pass fewer free their half CU for the others -- measured 224 vs 248 us)
+        const int per_block = (npass + slots - 1) / slots;
+        const int grid = wv == 4 ? std::min(npass, slots) : (npass + per_block - 1) / per_block;
         const double rows = a.M;
         const double abytes = 2.0 * (rows * 256 * 2 + (a.Fo ? rows * FFN_F : 0.0) + 2.0 * 256 * FFN_F);
         ProfScope ps(h, st, GE2E_K_FFN, 2.0 * rows * 256 * FFN_F * 2.0, abytes);
-        if (a.Fo) { auto kern = ffn_chain_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem(), st, a, npass); }
-        else { auto kern = ffn_chain_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem(), st, a, npass); }
+        if (wv == 4) {
+            if (a.Fo) { auto kern = ffn_chain_kernel<T, true, 0, false, 4>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_smem<4>(), st, a, npass); }
+            else { auto kern = ffn_chain_kernel<T, false, 0, false, 4>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_smem<4>(), st, a, npass); }
+        } else {
+            if (a.Fo) { auto kern = ffn_chain_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem<8>(), st, a, npass); }
+            else { auto kern = ffn_chain_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem<8>(), st, a, npass); }
+        }
         return 0;
     }
 }
@@ -560,7 +581,10 @@ struct SideCtx {
     hipEvent_t ev() {
         if (next == set->ev.size()) {
             hipEvent_t e = nullptr;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = 1; return nullptr; }
+            // device-side fences between two streams of ONE device: no system-scope release (the kernels' own agent-scope release /
+            // acquire at dispatch boundaries orders the data)
+            static const unsigned flags = hipEventDisableTiming | (getenv("GE2E_EVENT_SYSFENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+            if (hipEventCreateWithFlags(&e, flags) != hipSuccess) { err = 1; return nullptr; }
             set->ev.push_back(e);
         }
         return set->ev[next++];
@@ -767,7 +791,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     if (e != hipSuccess) return fail_hip(h, e, "zero grads");
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
-    hipEvent_t g_set1 = nullptr, g_set2 = nullptr, g_dF = nullptr, g_dQKV = nullptr;   // last side-stream reader of a buffer
+    // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
+    hipEvent_t g_set1[2] = {nullptr, nullptr}, g_set2[2] = {nullptr, nullptr}, g_dF[2] = {nullptr, nullptr}, g_dQKV[3] = {nullptr, nullptr, nullptr};
     {
         TailArgs a{};
         a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
@@ -794,17 +819,19 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         const int Rl = last ? n : R, rmul = last ? t : 1;
         unsigned char* const b_dH = ws + (last ? L.c_dH : L.dHa);     // dL/d(layer output)
         unsigned char* const b_dHb = ws + (last ? L.c_dHb : L.dHb);
-        unsigned char* const b_dP = ws + (last ? L.c_dP : L.dP);
-        unsigned char* const b_dM = ws + (last ? L.c_dM : L.dM);
-        unsigned char* const b_dP2 = ws + (last ? L.c_dP2 : L.dP2);   // norm1-backward outputs (set 2)
-        unsigned char* const b_dM2 = ws + (last ? L.c_dM2 : L.dM2);
-        unsigned char* const b_dF = ws + (last ? L.c_dF : L.dF);
+        const int bs = l % L.nset, bq = l % L.nqkv;                   // this layer's buffer sets
+        unsigned char* const b_dP = ws + (last ? L.c_dP : L.dP[bs]);
+        unsigned char* const b_dM = ws + (last ? L.c_dM : L.dM[bs]);
+        unsigned char* const b_dP2 = ws + (last ? L.c_dP2 : L.dP2[bs]);   // norm1-backward outputs (set 2)
+        unsigned char* const b_dM2 = ws + (last ? L.c_dM2 : L.dM2[bs]);
+        unsigned char* const b_dF = ws + (last ? L.c_dF : L.dF[bs]);
+        unsigned char* const b_dQKV = ws + L.dQKV[bq];
         unsigned char* const b_dO = ws + (last ? L.c_dO : L.dO);
         const int ln_grid = std::min(2048, (Rl + 3) / 4);
         const Drop d_ff = make_drop(true, c.tf_dropout, seed, step, site_ff(l));
         const Drop d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
         const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
-        sc.wait(g_set1);
+        if (!last) sc.wait(g_set1[bs]);                  // (the last layer's compact scratch is written once per backward)
         {   // norm2 backward
             LnBwdArgs a{};
             a.dy = b_dH; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
@@ -815,7 +842,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
         unsigned char* gm = d_ff.thr ? b_dM : b_dP;
-        sc.wait(g_dF);
+        if (!last) sc.wait(g_dF[bs]);
         {   // dF = (dG W2) masked by ReLU/dropout of the hidden.  (Fusing norm2's backward into this GEMM as it is fused into
             // dO below was measured and lost: its four column-group blocks each redo the LayerNorm prologue, 327 vs 260 us.)
             GemmArgs a{};
@@ -829,14 +856,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
-            g_set1 = sc.mark();
+            if (!last) g_set1[bs] = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
             a.R = Rl; a.N = c.ffn; a.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
-            g_dF = sc.mark();
+            if (!last) g_dF[bs] = sc.mark();
         }
         {   // dH1 = dPre2 + dF W1
             GemmArgs a{};
@@ -844,7 +871,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, a)));
         }
-        sc.wait(g_set2);
+        if (!last) sc.wait(g_set2[bs]);
         gm = d_sa.thr ? b_dM2 : b_dP2;
         GemmArgs ado{};        // dO = dA Wo
         ado.A = gm; ado.lda = d; ado.W = ws + L.w_outT[l]; ado.ldw = d; ado.C = b_dO; ado.ldc = d;
@@ -875,35 +902,35 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
             a.R = Rl; a.N = d; a.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
-            g_set2 = sc.mark();
+            if (!last) g_set2[bs] = sc.mark();
         }
-        sc.wait(g_dQKV);
+        sc.wait(g_dQKV[bq]);
         if (!last) {
             AttnArgs a{};
-            a.qkv = ws + L.qkv[l]; a.dout = b_dO; a.dqkv = ws + L.dQKV; a.T = t; a.H = c.heads; a.D = d;
+            a.qkv = ws + L.qkv[l]; a.dout = b_dO; a.dqkv = b_dQKV; a.T = t; a.H = c.heads; a.D = d;
             a.o = ws + L.o[l]; a.lse = (float*)(ws + L.lse[l]);
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, true, L.adelta != (size_t)-1 ? (float*)(ws + L.adelta) : nullptr));
             sc.fork();
             WgradArgs w{};
-            w.Y = ws + L.dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
+            w.Y = b_dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
             w.R = R; w.N = 3 * d; w.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
-            g_dQKV = sc.mark();
+            g_dQKV[bq] = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
-            g.A = ws + L.dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
+            g.A = b_dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
             g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP2; g.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, g)));
         } else {
             AttnQ0Args a{};   // one query per (utterance, head): dK, dV for every frame, dQ for frame 0
-            a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = ws + L.dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
+            a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = b_dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn_q0<T>(h, st, a, n, true));
             sc.fork();
             WgradArgs wkv{};  // k | v rows of in_proj_weight from every frame
-            wkv.Y = ws + L.dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
+            wkv.Y = b_dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
             wkv.dW = G(lp(l, L_IN_W)) + (size_t)d * d; wkv.ldw = d; wkv.db = G(lp(l, L_IN_B)) + d;
             wkv.R = R; wkv.N = 2 * d; wkv.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wkv, wpart)));
@@ -911,13 +938,13 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wq)));
-            g_dQKV = sc.mark();
+            g_dQKV[bq] = sc.mark();
             GemmArgs g0{};    // frame-0 addend: dPre1 + dQ0 Wq   (compact)
             g0.A = ws + L.c_dQ0; g0.lda = d; g0.W = ws + L.w_inT[l]; g0.ldw = 3 * d; g0.C = ws + L.c_tmp; g0.ldc = d;
             g0.M = n; g0.N = d; g0.K = d; g0.R = b_dP2; g0.ldr = d;
             CK((gemm128<T, EPI_ADD>(h, st, g0)));
             GemmArgs g{};     // dH(layer input) = dKV Wkv, plus the compact addend on frame-0 rows
-            g.A = ws + L.dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
+            g.A = b_dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
             g.C = ws + L.dHa; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
             CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
         }
@@ -1291,15 +1318,16 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
     else if (train && base == "rstd1") { *offset_bytes = L.rstd1[l]; *size_bytes = Rl * 4; }          // fp32
     else if (train && base == "rstd2") { *offset_bytes = L.rstd2[l]; *size_bytes = Rl * 4; }          // fp32
     else if (train && base == "lse" && !lastl) { *offset_bytes = L.lse[l]; *size_bytes = R * (size_t)h->cfg.heads * 4; }   // fp32
-    else if (train && base == "dP1") { *offset_bytes = L.dP; *size_bytes = R * d * e; }              // norm2-backward outputs (set 1)
-    else if (train && base == "dM1") { *offset_bytes = L.dM; *size_bytes = R * d * e; }
+    // backward scratch of FULL-SIZE layer l (name.l): the buffer set that layer uses, see Layout
+    else if (train && base == "dP1") { *offset_bytes = L.dP[l % L.nset]; *size_bytes = R * d * e; }  // norm2-backward outputs (set 1)
+    else if (train && base == "dM1") { *offset_bytes = L.dM[l % L.nset]; *size_bytes = R * d * e; }
     else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
-    else if (train && base == "dF") { *offset_bytes = L.dF; *size_bytes = R * (size_t)h->cfg.ffn * e; }
+    else if (train && base == "dF") { *offset_bytes = L.dF[l % L.nset]; *size_bytes = R * (size_t)h->cfg.ffn * e; }
     else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }
-    else if (train && base == "dP") { *offset_bytes = L.dP2; *size_bytes = R * d * e; }
-    else if (train && base == "dM") { *offset_bytes = L.dM2; *size_bytes = R * d * e; }
+    else if (train && base == "dP") { *offset_bytes = L.dP2[l % L.nset]; *size_bytes = R * d * e; }
+    else if (train && base == "dM") { *offset_bytes = L.dM2[l % L.nset]; *size_bytes = R * d * e; }
     else if (train && base == "dO") { *offset_bytes = L.dO; *size_bytes = R * d * e; }
-    else if (train && base == "dQKV") { *offset_bytes = L.dQKV; *size_bytes = R * 3 * d * e; }
+    else if (train && base == "dQKV") { *offset_bytes = L.dQKV[l % L.nqkv]; *size_bytes = R * 3 * d * e; }
     else return GE2E_EINVAL;
     return 0;
 }

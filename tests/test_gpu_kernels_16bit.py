@@ -188,18 +188,18 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
         assert err < tol, (nm, err)
 
     dx2, dg2, db2 = ln_bwd(dy, sv["h2"], sv["rstd2"], Pf[pre + "norm2.weight"], Pf[pre + "norm2.bias"])
-    dP1, dM1 = tap("dP1", (R, d)), tap("dM1", (R, d))
+    dP1, dM1 = tap(f"dP1.{l}", (R, d)), tap(f"dM1.{l}", (R, d))
     close(dP1, dx2, prec, "norm2 backward (ln_bwd_kernel) dpre")
     close(dM1, dx2 * keep_rows(O.drop_key(seed, 0, O.site_ff(l)), R, d, p) * scale_d, prec, "norm2 backward dmask")
     wclose(pre + "norm2.weight", dg2); wclose(pre + "norm2.bias", db2)
-    dF = tap("dF", (R, ffn))
+    dF = tap(f"dF.{l}", (R, ffn))
     close(dF, (dM1 @ W[pre + "linear2.weight"]) * (sv["f"] > 0).to(F64) * scale_d, prec, "dF = (dG W2) o mask (gemm_ws EPI_MASK)")
     wclose(pre + "linear2.weight", dM1.t() @ sv["f"]); wclose(pre + "linear2.bias", dM1.sum(0))
     wclose(pre + "linear1.weight", dF.t() @ sv["h1"]); wclose(pre + "linear1.bias", dF.sum(0))
     dHb = tap("dHb", (R, d))
     close(dHb, dP1 + dF @ W[pre + "linear1.weight"], prec, "dH1 = dPre2 + dF W1 (gemm_nt EPI_ADD, K = 1024)")
     dx1, dg1, db1 = ln_bwd(dHb, sv["h1"], sv["rstd1"], Pf[pre + "norm1.weight"], Pf[pre + "norm1.bias"])
-    dP2, dM2 = tap("dP", (R, d)), tap("dM", (R, d))
+    dP2, dM2 = tap(f"dP.{l}", (R, d)), tap(f"dM.{l}", (R, d))
     close(dP2, dx1, prec, "norm1 backward in the dO GEMM prologue (gemm_ws_lnbwd) dpre")
     close(dM2, dx1 * keep_rows(O.drop_key(seed, 0, O.site_sa(l)), R, d, p) * scale_d, prec, "norm1 backward dmask")
     wclose(pre + "norm1.weight", dg1); wclose(pre + "norm1.bias", db1)
@@ -216,7 +216,7 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     pdr = rt(prob * keep_a * scale_d, prec)
     dq, dk, dv = ds @ sv["k"], ds.transpose(-1, -2) @ sv["q"], pdr.transpose(-1, -2) @ do_h
     dqkv_ref = torch.cat([z.permute(0, 2, 1, 3).reshape(R, d) for z in (dq, dk, dv)], dim=1)
-    dQKV = tap("dQKV", (R, 3 * d))
+    dQKV = tap(f"dQKV.{l}", (R, 3 * d))
     close(dQKV, dqkv_ref, prec, "attention backward (attn_bwd_kernel)", l2=0.4, ulps=6.0)
     wclose(pre + "self_attn.in_proj_weight", dQKV.t() @ sv["h_in"]); wclose(pre + "self_attn.in_proj_bias", dQKV.sum(0))
     dHa = tap("dHa", (R, d))

@@ -15,22 +15,22 @@ __global__ void fill_f32(float* p, size_t n, unsigned seed, float base) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         p[i] = base + (((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f) * 0.1f;
 }
-template <typename K> float time_kernel(K launch, int iters = 10) {
+template <typename K> float time_kernel(K launch, int iters = 20) {
     hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
-    for (int i = 0; i < 2; ++i) launch();
+    for (int i = 0; i < 10; ++i) launch();
     CHECK(hipEventRecord(a));
     for (int i = 0; i < iters; ++i) launch();
     CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
     float ms; CHECK(hipEventElapsedTime(&ms, a, b)); CHECK(hipGetLastError());
     return ms / iters;
 }
-template <bool STORE, int ABL> void run(const char* tag, FfnArgs a, int grid_cap) {
-    auto kern = ffn_chain_kernel<bf16_t, STORE, ABL>;
-    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ffn_smem()));
-    const int npass = (a.M + 255) / 256, grid = std::min(grid_cap, npass);
+template <bool STORE, int ABL, int WV = 8> void run(const char* tag, FfnArgs a, int grid_cap) {
+    auto kern = ffn_chain_kernel<bf16_t, STORE, ABL, STORE && WV == 8, WV>;
+    CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ffn_smem<WV>()));
+    const int npass = (a.M + 32 * WV - 1) / (32 * WV), grid = std::min(grid_cap, npass);
     if (!STORE) a.Fo = nullptr;
-    float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), ffn_smem(), 0, a, npass); });
-    printf("%-40s store_f=%d abl=%2d grid=%3d  %8.1f us  %7.1f TF/s\n", tag, (int)STORE, ABL, grid, ms * 1e3, 4.0 * a.M * 256 * 1024 / ms / 1e9);
+    float ms = time_kernel([&]() { hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WV), ffn_smem<WV>(), 0, a, npass); });
+    printf("%-40s wv=%d store_f=%d abl=%2d grid=%3d  %8.1f us  %7.1f TF/s\n", tag, WV, (int)STORE, ABL, grid, ms * 1e3, 4.0 * a.M * 256 * 1024 / ms / 1e9);
 }
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 153600;
@@ -45,8 +45,25 @@ int main(int argc, char** argv) {
     a.A = A; a.lda = 256; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Fo = F; a.ldf = 1024; a.C = C; a.ldc = 256;
     a.gamma = ga; a.beta = be; a.rstd = rstd; a.eps = 1e-5f; a.M = M; a.drow_mul = 1;
     FfnArgs ad = a; ad.drop1 = Drop{12345u, 6553u, 1.1111f}; ad.drop2 = Drop{54321u, 6553u, 1.1111f};
+    for (int rep = 0; rep < 3; ++rep) {          // A/B of the two block shapes, interleaved (the clocks ramp over the first launches)
+        run<false, 0>("eval  8-wave, 200 blocks", a, 200);
+        run<false, 0, 4>("eval  4-wave, 512 blocks", a, 512);
+        run<true, 0>("train 8-wave, 200 blocks", ad, 200);
+        run<true, 0, 4>("train 4-wave, 512 blocks", ad, 512);
+    }
     run<false, 0>("eval  full", a, 256);
     run<false, 0>("eval  full, 200 blocks", a, 200);
+    run<false, 0, 4>("eval  4-wave blocks, 512", a, 512);
+    run<false, 0, 4>("eval  4-wave blocks, 400", a, 400);
+    run<false, 0, 4>("eval  4-wave blocks, 256 (1 per CU)", a, 256);
+    run<true, 0, 4>("train 4-wave blocks, 512", ad, 512);
+    run<true, 0, 4>("train 4-wave blocks, 400", ad, 400);
+    run<true, 0, 4>("train 4-wave blocks, 256 (1 per CU)", ad, 256);
+    run<true, 1, 4>("train 4-wave no MFMA", ad, 400);
+    run<true, 2, 4>("train 4-wave no DMA", ad, 400);
+    run<true, 8, 4>("train 4-wave no barrier", ad, 400);
+    run<true, 16, 4>("train 4-wave no hidden epilogue math", ad, 400);
+    run<true, 64, 4>("train 4-wave no pass epilogue", ad, 400);
     run<true, 0>("train full (dropout on, hidden stored)", ad, 256);
     run<true, 0>("train full, 200 blocks", ad, 200);
     run<true, 0>("train, dropout off (thr = 0), hidden stored", a, 256);
