@@ -51,6 +51,19 @@ constexpr int FFN_F = 1024;        // hidden width (4 x 256)
 //           top of the stage.  The two waves of a SIMD then belong to different blocks: no barrier couples them, so one block's
 //           vector-ALU phases, pass prologue (h1 loads) and pass epilogue (LayerNorm, stores) run under the other's MFMAs.  The
 //           weights stream twice per CU (2 x 32 KB per stage time: still under half of the CU's L2 ingest rate).
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E - 1>{})
+template <int B, int E, typename F> __device__ __forceinline__ void ffn_static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); ffn_static_for<B + 1, E>(f); }
+}
+// LDS fragment read / counted wait as opaque instructions: the compiler's own wait insertion drains the LDS queue (lgkmcnt(0))
+// every few fragments of a read-ahead ring instead of waiting for the oldest read only; these keep FRD reads in flight.  The wait
+// names the fragment it releases, so the MFMAs that consume it stay behind it.  (Compiler-placed LDS operations in between only
+// make these waits stricter: the counter is in order, and more younger operations mean the oldest retires earlier than counted.)
+template <int OFF> __device__ __forceinline__ void ffn_lds_read(u32x4& f, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void ffn_lds_wait(u32x4& f) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(N)); }
+
 template <int WV> constexpr int ffn_nstg() { return WV == 8 ? 4 : 2; }
 template <int WV> constexpr size_t ffn_smem() { return (size_t)ffn_nstg<WV>() * FFN_SLOT + (FFN_F + 3 * 256) * 4; }
 
@@ -262,7 +275,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                     const int col = c * 32 + 8 * g + 4 * ht;
                     if constexpr ((ABL & 16) == 0) {
                     h[rt][ht] += *(const f32x4*)(smem + bb + 16 * ht);
-                    (void)relu_drop_apply4(p.drop1, (uint32_t)row * drm * (uint32_t)FFN_F + (uint32_t)col, h[rt][ht]);
+                    if constexpr (STORE_F) (void)relu_drop_apply4(p.drop1, (uint32_t)row * drm * (uint32_t)FFN_F + (uint32_t)col, h[rt][ht]);
+                    else (void)relu_drop_apply4(Drop{0u, 0u, 1.0f}, 0u, h[rt][ht]);      // the eval kernel: no dropout (the launcher checks)
                     }
                 }
                 hp[rt] = pack_acc<T>(h[rt][0], h[rt][1]);      // 8 consecutive hidden units 32c + 8g .. + 7 of row (rt, i)
@@ -309,6 +323,16 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         };
         constexpr int NCHR = (ABL & 32) ? 0 : NCH;
         if constexpr (WV == 4) {
+            // The 32 fragments of a stage -- W1 (kg, ht) for kg = 0..7, then W2 (q, hh) for q = 0..7 -- go through a ring of FRB
+            // registers, read FRD = FRB - 1 fragments (2 MFMAs = 32 matrix-pipe cycles each) ahead of their use: an LDS read
+            // issued one 4-MFMA group ahead (the 8-wave loops) is waited for after ~32-64 cycles, well inside its latency.
+            constexpr int FRB = 6, FRD = FRB - 1;
+            u32x4 fr[FRB];
+            auto rd = [&](auto J) {
+                constexpr int j = decltype(J)::value;
+                if constexpr (j < 16) ffn_lds_read<(j & 1) * 2048 + (j >> 3) * 256>(fr[j % FRB], a1[(j >> 1) & 3]);
+                else if constexpr (j < 32) ffn_lds_read<((j - 16) >> 1) * 2048>(fr[j % FRB], a2[j & 1]);
+            };
 #pragma unroll 1
             for (int c = 0; c < NCHR; ++c) {
                 f32x4 h[2][2];
@@ -316,10 +340,26 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 if (c > 0) publish_next();             // stage 0 was published by the pass-start barrier
                 else { issue(); __builtin_amdgcn_sched_barrier(0); }
                 stage_bases(c & 1, a1, a2);            // NCH is even: stage c of every pass sits in slot c & 1
-                read_w1(a1, 0, wA);
-                prod1(h, a1, a2);
+                ffn_static_for<0, FRD>(rd);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) { h[rt][0] = f32x4{0, 0, 0, 0}; h[rt][1] = f32x4{0, 0, 0, 0}; }
+                ffn_static_for<0, 16>([&](auto J) {    // product 1: hidden tile j & 1, k-group j >> 1
+                    constexpr int j = decltype(J)::value;
+                    rd(std::integral_constant<int, j + FRD>{});
+                    ffn_lds_wait<FRD>(fr[j % FRB]);
+                    h[0][j & 1] = mm(fr[j % FRB], af[0][j >> 1], h[0][j & 1]);
+                    h[1][j & 1] = mm(fr[j % FRB], af[1][j >> 1], h[1][j & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
                 hidden_epilogue(h, hp, c);
-                prod2(hp, a2, a1);
+                ffn_static_for<16, 32>([&](auto J) {   // product 2: output tile j - 16
+                    constexpr int j = decltype(J)::value;
+                    rd(std::integral_constant<int, j + FRD>{});
+                    ffn_lds_wait<(j + FRD < 32 ? FRD : 31 - j)>(fr[j % FRB]);
+                    oacc[0][j - 16] = mm(fr[j % FRB], hp[0], oacc[0][j - 16]);
+                    oacc[1][j - 16] = mm(fr[j % FRB], hp[1], oacc[1][j - 16]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
             }
         } else if (!lag) {
 #pragma unroll 1
@@ -401,7 +441,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 for (int hh = 0; hh < 2; ++hh) {
                     const int col = 32 * kg + 8 * g + 4 * hh;
                     f32x4 v = oacc[rt][2 * kg + hh] + *(const f32x4*)(smem + lb + (32 * kg + 4 * hh) * 4);
-                    drop_apply4(p.drop2, (uint32_t)row * drm * 256u + (uint32_t)col, v);
+                    if constexpr (STORE_F) drop_apply4(p.drop2, (uint32_t)row * drm * 256u + (uint32_t)col, v);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] += to_f32(res[4 * hh + r]);
                     oacc[rt][2 * kg + hh] = v;

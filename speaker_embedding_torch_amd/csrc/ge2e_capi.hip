@@ -351,9 +351,15 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
             if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device >= 0 ? h->device : 0) != hipSuccess || n <= 0) n = 256;
             h->num_cus = n;
         }
-        // block shape (ffn.cuh): two 4-wave blocks per CU by default (alone: eval 172 vs 191 us, train 224 vs 230 us; the bf16 training
-        // step 4.09 vs 4.12 ms); GE2E_FFN_WV=8 selects the one-block-per-CU shape
-        static const int wv = getenv("GE2E_FFN_WV") && atoi(getenv("GE2E_FFN_WV")) == 8 ? 8 : 4;
+        // Block shape (ffn.cuh).  In steady state the 8-wave block (one per CU, staggered waves) gets more rows per CU and
+        // microsecond -- eval 3.9 vs 3.7, train 3.2 vs 2.7 -- but its 256-row passes quantise: 600 passes (the headline batch) on
+        // 256 CUs take three rounds with a quarter of the chip idle, where 1200 half-size passes on 512 half-CU slots flow
+        // (measured alone: eval 160 vs 195 us, train 224 vs 238 us; 768,000 rows, 3000 passes: 826 vs 804 us).  Take the 8-wave
+        // shape when its rounds are full enough to keep its per-CU advantage.  GE2E_FFN_WV = 4 / 8 forces one.
+        static const int wv_env = getenv("GE2E_FFN_WV") ? atoi(getenv("GE2E_FFN_WV")) : 0;
+        const int np8 = (a.M + 255) / 256, rounds8 = (np8 + h->num_cus - 1) / h->num_cus;
+        const double fill8 = (double)np8 / ((double)rounds8 * h->num_cus);
+        const int wv = wv_env == 4 || wv_env == 8 ? wv_env : (fill8 >= (a.Fo ? 0.84 : 0.95) ? 8 : 4);
         const int rows_pass = wv == 4 ? 128 : 256, slots = wv == 4 ? 2 * h->num_cus : h->num_cus;
         const int npass = (a.M + rows_pass - 1) / rows_pass;
         // every block runs ceil(npass / slots) passes: a grid of ceil(npass / that) blocks finishes at the same time as a full

@@ -301,6 +301,22 @@ def test_multislice_inference_fp32_and_bf16(mods):
         assert e.shape == (8, 256) and rel_l2(e, ref) < tol
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_ffn_block_shapes_give_the_same_rows(mods, prec):
+    """The chained FFN kernel has two block shapes (ffn.cuh: one 8-wave block or two 4-wave blocks per CU) and the launcher picks one
+    by the number of rows; both accumulate in the same order, so an utterance's d-vector must not change BITWISE with the batch it
+    sits in: 400 x 160 rows (250 passes of 256 rows fill 256 CUs: the 8-wave shape) against the first 40 alone (the 4-wave shape)."""
+    GE2E, _ = mods
+    m, _, _ = build(GE2E, prec, 0.1)
+    m.eval()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.randn(400, 80, 160, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    with torch.no_grad():
+        e_big = m(x)
+        e_small = m(x[:40].contiguous())
+    assert torch.equal(e_big[:40], e_small)
+
+
 # ------------------------------------------------------------------------------------------ full size properties
 @pytest.mark.parametrize("prec,S,P,T", [("bf16", 64, 15, 160), ("fp32", 64, 15, 160),
                                         ("fp16", 256, 10, 180), ("bf16", 256, 10, 180)])

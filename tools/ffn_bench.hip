@@ -67,7 +67,6 @@ int main(int argc, char** argv) {
     run<true, 0>("train full (dropout on, hidden stored)", ad, 256);
     run<true, 0>("train full, 200 blocks", ad, 200);
     run<true, 0>("train, dropout off (thr = 0), hidden stored", a, 256);
-    { FfnArgs an = ad; run<false, 0>("dropout on, hidden NOT stored (eval kernel)", an, 256); }
     run<true, 1>("train no MFMA", ad, 256);
     run<true, 2>("train no DMA", ad, 256);
     run<true, 8>("train no barrier", ad, 256);
