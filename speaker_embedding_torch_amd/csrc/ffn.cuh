@@ -35,6 +35,8 @@ struct FfnArgs {
     const void* W2;                // [256][F] of T   (linear2.weight, k-contiguous)
     const float* b2;               // [256]
     void* Fo; int ldf;             // hidden out [M, F] of T (train), or null
+    unsigned char* Mb;             // train: [M][F / 8] "kept and positive" bits of the hidden, read by the dF GEMM of the backward; hidden
+                                   // unit u sits in byte ffn_mask_byte(u), bit u & 7 of its row (gemm_ws.cuh EPI_MASKBITS reads the same map)
     void* C; int ldc;              // h2 [M, 256] of T
     const float* gamma; const float* beta; float* rstd; float eps;
     Drop drop1, drop2;             // dropout after ReLU (counter row * F + col), dropout2 (counter row * 256 + col)
@@ -42,6 +44,9 @@ struct FfnArgs {
     int M;
 };
 
+// Mask-bit layout of a row (128 bytes): the chained kernel's lane (i, g) produces, stage after stage (32 units each), the bits of
+// units 32 c + 8 g .. + 7; four consecutive stages are gathered into one 32-bit store, so those four bytes are contiguous:
+__host__ __device__ constexpr int ffn_mask_byte(int u) { return 16 * (u >> 7) + 4 * ((u >> 3) & 3) + ((u >> 5) & 3); }
 constexpr int FFN_SLOT = 32 * 1024;
 constexpr int FFN_F = 1024;        // hidden width (4 x 256)
 // Two block shapes:
@@ -78,7 +83,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
     constexpr int NCH = FFN_F / 32;              // stages per pass
     constexpr int NSTG = ffn_nstg<WV>(), D = NSTG - 1;
     constexpr int NDMA = 32 / WV;                // DMA instructions per wave and stage
-    constexpr int NST = STORE_F ? 2 : 0;         // hidden-store instructions per wave and stage
+    constexpr int NST = STORE_F ? 2 : 0;         // hidden-store instructions per wave and stage that the counted waits rely on (the two
+                                                 // 16-byte value stores; every fourth stage adds two mask words: a count may be too small)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Ring = smem;                                      // [NSTG][32 KB]: W1 slice | W2 slice
     float* const B1s = (float*)(smem + NSTG * FFN_SLOT);                   // [1024]
@@ -226,6 +232,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) oacc[rt][nt] = f32x4{0, 0, 0, 0};
+        uint32_t macc[2] = {0u, 0u};                   // train: mask bytes of four stages (see ffn_mask_byte)
 
         // The fragment reads run one group (2 fragments = 4 MFMAs) ahead of the matrix pipe: wA / wB alternate, and every
         // product ends by reading the first fragments of the product that follows it in program order into wA.
@@ -286,6 +293,24 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                         asm volatile("" : "+v"(fo));
                         __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + (size_t)fo * 16));
                     }
+                    // "stored value != 0" of the 8 packed 16-bit values (they are +0 or positive): a packed min against 1 leaves
+                    // bit 0 / bit 16 of word k for units 2k / 2k + 1 (building the bits from the compares costs twice the VALU)
+                    uint32_t tb = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {      // (as an instruction: the compiler expands min(x, 1) into compares and selects)
+                        uint32_t m2;
+                        asm("v_pk_min_u16 %0, %1, %2" : "=v"(m2) : "v"(hp[rt][k]), "s"(0x00010001u));
+                        tb |= m2 << (2 * k);
+                    }
+                    macc[rt] |= ((tb | (tb >> 15)) & 0xFFu) << (8 * (c & 3));
+                    if ((c & 3) == 3) {                // four stages' bytes = one word: row * 128 + 16 (c >> 2) + 4 g
+                        if (row < p.M) {
+                            unsigned mo = (unsigned)row * (unsigned)(FFN_F / 32) + (unsigned)(c + g - 3);     // in words: 4 (c >> 2) + g
+                            asm volatile("" : "+v"(mo));
+                            ((uint32_t*)p.Mb)[mo] = macc[rt];
+                        }
+                        macc[rt] = 0;
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -312,9 +337,14 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         // issued since are outstanding
         // (WV = 4, D = 1: the barrier sits at the top of stage c and publishes stage c itself, whose DMAs are older than the previous
         // stage's hidden stores only; the refill that follows goes to the slot of stage c - 1)
+        // The count includes the hidden stores issued since -- which a wave whose 16-row tile lies beyond M SKIPS (its store sits
+        // behind an exec-zero branch): such a wave (only in the last, partial pass) waits by the DMAs alone, which is correct
+        // however many of its stores were issued (a count may be too small, never too large).
         constexpr int PUBW = WV == 8 ? (D - 2) * NDMA + (D - 1) * NST : NST;
+        constexpr int PUBW_DMA = WV == 8 ? (D - 2) * NDMA : 0;
+        const bool all_rows = m0 + 32 <= p.M;       // wave-uniform
         auto publish_next = [&]() {
-            wait_vmcnt<PUBW>();
+            if (all_rows) wait_vmcnt<PUBW>(); else wait_vmcnt<PUBW_DMA>();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if constexpr ((ABL & 8) == 0) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);

@@ -3,6 +3,7 @@
 // out_proj GEMM+LN, FFN1 GEMM, FFN2 GEMM+LN} + tail.  Everything is enqueued on the caller's stream.
 #include "../../include/ge2e_hip.h"
 
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
@@ -107,6 +108,8 @@ struct Layout {
     size_t xt = 0;               // packed mel: [R][KP] of T (row-major copy of the channels-first fp32 input)
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
+    size_t fbits[MAX_LAYERS];    // [R, ffn / 8] bytes: "stored FFN hidden > 0", one bit per element (train, 16-bit modes, full layers;
+                                 // written by the chained FFN kernel, read by the backward's dF GEMM instead of the hidden itself)
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
     size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
@@ -153,6 +156,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
             L.f[l] = take(Rl * f * e);      L.h2[l] = take(Rl * d * e);
             L.rstd2[l] = take(Rl * 4);
             L.lse[l] = l == last ? (size_t)-1 : take(R * (size_t)c.heads * 4);
+            L.fbits[l] = (l == last || e != 2 || f % 128 != 0) ? (size_t)-1 : take(R * (f / 8));
         }
     } else {        // eval: layers reuse one set of buffers; h2 overwrites the layer input
         const size_t qkv = take(R * 3 * d * e);
@@ -160,9 +164,9 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         if (c.layers > 1) { o = take(R * d * e); h1 = take(R * d * e); ff = take(R * f * e); }
         for (int l = 0; l < last; ++l) {
             L.qkv[l] = qkv; L.o[l] = o; L.h1[l] = h1; L.f[l] = ff; L.h2[l] = L.h0;
-            L.rstd1[l] = L.rstd2[l] = L.lse[l] = (size_t)-1;
+            L.rstd1[l] = L.rstd2[l] = L.lse[l] = L.fbits[l] = (size_t)-1;
         }
-        L.lse[last] = (size_t)-1;
+        L.lse[last] = L.fbits[last] = (size_t)-1;
         L.qkv[last] = qkv; L.o[last] = take((size_t)n * d * e); L.h1[last] = take((size_t)n * d * e);
         L.f[last] = take((size_t)n * f * e); L.h2[last] = take((size_t)n * d * e);
         L.rstd1[last] = L.rstd2[last] = (size_t)-1;
@@ -228,6 +232,12 @@ struct ProfScope {
 // ------------------------------------------------------------------------------------------ launches
 // Dynamic LDS above 48 KB needs the function attribute raised first.  The largest size ever requested is remembered per call
 // site (a call site launches one kernel instantiation); a later, larger request (runtime-sized LDS) raises it again.
+//
+// Armed launches (SideCtx::arm): while a fence event is armed for a stream, every kernel launched on that stream carries it as its
+// completion ("stop") event, so the event completes with the LAST such kernel and no separate marker packet follows it in the
+// queue.  A recorded marker costs the main chain ~6 us of idle queue per fence (rocprofv3 timeline); a bound event costs nothing.
+struct ArmedEvent { hipEvent_t ev = nullptr; hipStream_t on_stream = nullptr; int launches = 0; };
+static thread_local ArmedEvent tl_armed;
 #define GE2E_LAUNCH(h, kern, grid, block, smem, st, ...)                                                   \
     do {                                                                                                    \
         static std::atomic<size_t> attr_max{(size_t)48 * 1024};                                             \
@@ -236,6 +246,10 @@ struct ProfScope {
             if (ea != hipSuccess) return fail_hip(h, ea, "hipFuncSetAttribute " #kern);                     \
             attr_max.store((size_t)(smem), std::memory_order_relaxed);                                      \
         }                                                                                                   \
+        if (tl_armed.ev && tl_armed.on_stream == (st)) {                                                           \
+            hipExtLaunchKernelGGL(kern, grid, block, smem, st, nullptr, tl_armed.ev, 0, __VA_ARGS__);       \
+            ++tl_armed.launches;                                                                            \
+        } else                                                                                              \
         hipLaunchKernelGGL(kern, grid, block, smem, st, __VA_ARGS__);                                       \
         hipError_t el = hipGetLastError();                                                                  \
         if (el != hipSuccess) return fail_hip(h, el, #kern);                                                \
@@ -275,13 +289,15 @@ inline bool ws_shape(const GemmArgs& a) {
 template <typename T, int EPI>
 int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK);
+    if (EPI == EPI_MASKBITS && (a.N % 128 != 0 || a.ldr % 16 != 0)) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: mask-bit rows are whole 16-byte words");
     if (EPI == EPI_LN && a.N != 256) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: the LayerNorm epilogue needs N == 256");
     if (reads_r && a.ldr % 8 != 0) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: the addend rows must be 16-byte aligned");
     const int cg = a.N / 256, ntiles = (a.M + 15) / 16;
     int parts = (512 / cg) / 8 * 8;                       // two resident blocks per CU
     if (parts > (ntiles + 7) / 8 * 8) parts = (ntiles + 7) / 8 * 8;
     if (parts < 8) parts = 8;
-    const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0));
+    const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0)) +
+                          (EPI == EPI_MASKBITS ? (double)a.M * a.N / 8.0 : 0.0);
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
     auto kern = gemm_ws_kernel<T, EPI, 256>;
     GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_smem<EPI, 256>()), st, a, parts, ntiles);
@@ -368,7 +384,7 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         const int per_block = (npass + slots - 1) / slots;
         const int grid = wv == 4 ? std::min(npass, slots) : (npass + per_block - 1) / per_block;
         const double rows = a.M;
-        const double abytes = 2.0 * (rows * 256 * 2 + (a.Fo ? rows * FFN_F : 0.0) + 2.0 * 256 * FFN_F);
+        const double abytes = 2.0 * (rows * 256 * 2 + (a.Fo ? rows * FFN_F : 0.0) + 2.0 * 256 * FFN_F) + (a.Fo ? rows * FFN_F / 8 : 0.0);
         ProfScope ps(h, st, GE2E_K_FFN, 2.0 * rows * 256 * FFN_F * 2.0, abytes);
         if (wv == 4) {
             if (a.Fo) { auto kern = ffn_chain_kernel<T, true, 0, false, 4>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_smem<4>(), st, a, npass); }
@@ -596,9 +612,22 @@ struct SideCtx {
         return set->ev[next++];
     }
     hipStream_t wstream() const { return on ? side : main_st; }
+    // arm(): the main-stream kernels launched from here to the next fork() carry that fork's fence as their completion event
+    // (GE2E_LAUNCH), so fork() only has to make the side stream wait for it
+    void arm() {
+        if (!on || bind_off()) return;
+        tl_armed = ArmedEvent{ev(), main_st, 0};
+    }
+    static bool bind_off() { static const bool off = getenv("GE2E_NO_EVENT_BIND") != nullptr; return off; }
     void fork() {                           // side waits for everything enqueued on main so far
         if (!on) return;
-        hipEvent_t e = ev();
+        const ArmedEvent a = tl_armed;
+        tl_armed = ArmedEvent{};
+        if (a.ev && a.launches > 0) {       // bound to the last kernel before this point
+            if (hipStreamWaitEvent(side, a.ev, 0) != hipSuccess) err = 1;
+            return;
+        }
+        hipEvent_t e = a.ev ? a.ev : ev();  // (an armed event no kernel took is still unrecorded: use it here)
         if (!e || hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) err = 1;
     }
     hipEvent_t mark() {                     // event after everything enqueued on side so far
@@ -615,6 +644,7 @@ struct SideCtx {
     // side stream was given -- the caller may free the gradient buffer and the workspace right after the call -- and the
     // set's `done` event marks the point after which its fence events may be recorded again.
     void join() {
+        tl_armed = ArmedEvent{};            // (an error return between arm() and fork())
         if (!on) return;
         hipEvent_t e = mark();
         wait(e);
@@ -728,6 +758,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             FfnArgs a{};
             a.A = ws + L.h1[l]; a.lda = d; a.W1 = ws + L.w_l1[l]; a.b1 = P[lp(l, L_L1_B)]; a.W2 = ws + L.w_l2[l]; a.b2 = P[lp(l, L_L2_B)];
             a.Fo = train ? ws + L.f[l] : nullptr; a.ldf = c.ffn; a.C = ws + L.h2[l]; a.ldc = d;
+            a.Mb = train ? ws + L.fbits[l] : nullptr;
             a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)]; a.eps = c.ln_eps;
             a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
             a.drop1 = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
@@ -766,6 +797,8 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
     return 0;
 }
 
+inline bool maskbits_on() { static const bool off = getenv("GE2E_NO_MASKBITS") != nullptr; return !off; }
+inline bool prenet_on_side() { static const bool on = getenv("GE2E_PRENET_WGRAD_SIDE") != nullptr; return on; }
 template <typename T>
 int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
@@ -808,6 +841,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         a.d_emb = d_emb; a.d_raw = (float*)(ws + L.d_raw); a.dH = ws + L.c_dH;
         a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dwq = G(p_proj_w(c)); a.dbq = G(p_proj_b(c));
         auto kern = tail_bwd_kernel<T>;
+        sc.arm();
         GE2E_LAUNCH(h, kern, dim3((n / samples + TAIL_RB - 1) / TAIL_RB), dim3(256), 0, st, a);
         sc.fork();                                        // projection weight gradient: off the critical chain
         GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, wst, a);
@@ -854,10 +888,18 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             GemmArgs a{};
             a.A = gm; a.lda = d; a.W = ws + L.w_l2T[l]; a.ldw = d; a.C = b_dF; a.ldc = c.ffn;
             a.M = Rl; a.N = c.ffn; a.K = d; a.R = ws + L.f[l]; a.ldr = c.ffn; a.mask_scale = d_fh.scale;
+            sc.arm();
+            // a layer whose forward went through the chained FFN kernel left the mask as bits: 1/16 of the bytes of the hidden
+            bool bits = false;
+            if constexpr (sizeof(T) == 2) bits = L.fbits[l] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && ws_shape(a) && maskbits_on();
+            if (bits) {
+                a.R = ws + L.fbits[l]; a.ldr = c.ffn / 8;
+                if constexpr (sizeof(T) == 2) CK((launch_gemm_ws<T, EPI_MASKBITS>(h, st, a)));
+            } else
             CK((gemm128<T, EPI_MASK>(h, st, a)));
         }
         sc.fork();
-        {
+        {   // (started right after norm2's backward instead, next to the dF GEMM that streams the same gm and f: no gain, 4.10 vs 4.10 ms)
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn;
@@ -882,6 +924,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         GemmArgs ado{};        // dO = dA Wo
         ado.A = gm; ado.lda = d; ado.W = ws + L.w_outT[l]; ado.ldw = d; ado.C = b_dO; ado.ldc = d;
         ado.M = Rl; ado.N = d; ado.K = d;
+        sc.arm();
         if (ws_epilogue<T, EPI_MASK>() && ws_shape(ado) && lnfuse_on()) {
             // norm1 backward rides in the prologue of the dO GEMM
             LnFuseArgs f{};
@@ -917,6 +960,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.o = ws + L.o[l]; a.lse = (float*)(ws + L.lse[l]);
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
+            sc.arm();
             CK(launch_attn<T>(h, st, a, n, true, L.adelta != (size_t)-1 ? (float*)(ws + L.adelta) : nullptr));
             sc.fork();
             WgradArgs w{};
@@ -933,6 +977,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = b_dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
+            sc.arm();
             CK(launch_attn_q0<T>(h, st, a, n, true));
             sc.fork();
             WgradArgs wkv{};  // k | v rows of in_proj_weight from every frame
@@ -965,11 +1010,13 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
         CK((gemm128<T, EPI_PRENET_BWD>(h, st, a)));
-        sc.fork();
+        // the last weight gradient stays on the MAIN stream: on the side stream it would start a fence later and the join would
+        // wait for it, while the side stream's own last job (layer 0's in_proj gradient) ends about when this GEMM does
         WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
         w.Y = ws + L.dHa; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
-        CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
+        if (prenet_on_side()) { sc.fork(); CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart))); }
+        else CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));            // (no split-K scratch here: wpart belongs to the side stream)
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
     }
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again

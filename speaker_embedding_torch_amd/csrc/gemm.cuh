@@ -11,7 +11,8 @@
 
 namespace ge2e {
 
-enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_ADD_ROW0 };
+enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_ADD_ROW0,
+       EPI_MASKBITS /* EPI_MASK with the mask as one BIT per element: R = [M][ldr bytes], bits in the byte order of ffn.cuh ffn_mask_byte (gemm_ws only) */ };
 enum { ALOAD_ROW = 0 };     // operand rows are read row-major (the mel batch is packed to rows first: mel_pack_kernel)
 
 struct GemmArgs {

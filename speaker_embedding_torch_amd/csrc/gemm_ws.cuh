@@ -26,6 +26,9 @@ typedef const __attribute__((address_space(1))) void gbl_cvoid_t;
 __device__ __forceinline__ void glds16(const void* g, unsigned char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)lds_wave_base, 16, 0, 0);
 }
+__device__ __forceinline__ void glds4(const void* g, unsigned char* lds_wave_base) {      // 4 B per lane: base + lane * 4
+    __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)g, (lds_void_t*)lds_wave_base, 4, 0, 0);
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int WS_NSTG = 4;     // ring slots
@@ -34,7 +37,8 @@ constexpr int WS_D = 3;        // tiles in flight ahead of the one being consume
 template <int EPI, int K_>
 constexpr size_t gemm_ws_smem() {
     constexpr bool HAS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_LN);
-    return (size_t)WS_NSTG * 16 * K_ * 2 + (HAS_R ? (size_t)4 * WS_NSTG * 2048 : 0) + 4 * 2048 + (EPI == EPI_LN ? 3 * 1024 + 2 * 4 * 16 * 8 : 0);
+    return (size_t)WS_NSTG * 16 * K_ * 2 + (HAS_R ? (size_t)4 * WS_NSTG * 2048 : EPI == EPI_MASKBITS ? (size_t)4 * WS_NSTG * 256 : 0) + 4 * 2048 +
+           (EPI == EPI_LN ? 3 * 1024 + 2 * 4 * 16 * 8 : 0);
 }
 
 // grid = 8 * (N / 256) * (parts / 8) blocks; `parts` (multiple of 8) row partitions, `ntiles` = ceil(M / 16)
@@ -47,14 +51,15 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
     constexpr int RPI = 64 / CPR;                // A rows per DMA instruction (2 / 4)
     constexpr int NA = 4 / RPI;                  // A DMA instructions per wave and tile (4 rows per wave)
     constexpr bool HAS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_LN);
-    constexpr int NR = HAS_R ? 2 : 0;            // R DMA instructions per wave and tile (16 rows x 128 B)
+    constexpr bool HAS_B = (EPI == EPI_MASKBITS);   // the mask as bits: 16 rows x 16 B per wave and tile (the wave uses 8 B of each row)
+    constexpr int NR = HAS_R ? 2 : (HAS_B ? 1 : 0);   // R DMA instructions per wave and tile (16 rows x 128 B; bits: one 4-byte-per-lane piece)
     constexpr int ATILE = 16 * ROWB;
     constexpr int D = WS_D, NSTG = WS_NSTG;
     static_assert(ROWB % 256 == 0, "K must be a multiple of 128");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const As = smem;                                         // [NSTG][16][ROWB]
     unsigned char* const Rs = smem + NSTG * ATILE;                          // [4][NSTG][2048]
-    unsigned char* const Os = Rs + (HAS_R ? 4 * NSTG * 2048 : 0);           // [4][2048]
+    unsigned char* const Os = Rs + (HAS_R ? 4 * NSTG * 2048 : HAS_B ? 4 * NSTG * 256 : 0);   // [4][2048]
     float* const Ls = (float*)(Os + 4 * 2048);                              // EPI_LN: bias, gamma, beta [3][256]
     float* const Xs = Ls + 3 * 256;                                         // EPI_LN: [2][4 waves][16 rows] (mean, M2)
 
@@ -118,6 +123,10 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
                 int gr = r0 + r; gr = gr < last_row ? gr : last_row;
                 glds16(Rg + ((size_t)gr * p.ldr + n0) * 2 + c * 16, Rs + (wave * NSTG + s) * 2048 + q * 1024);
             }
+        }
+        if constexpr (HAS_B) {       // row lane >> 2, 32-bit word lane & 3 of the 128 mask bits around this wave's 64 columns
+            int gr = r0 + (lane >> 2); gr = gr < last_row ? gr : last_row;
+            glds4(Rg + (size_t)gr * p.ldr + (n0 >> 7) * 16 + (lane & 3) * 4, Rs + (wave * NSTG + s) * 256);
         }
     };
 
@@ -208,6 +217,15 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
                 const f32x4 m4 = load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
+            }
+            if constexpr (EPI == EPI_MASKBITS) {
+                // the 128 bits of row i around this wave's columns, in the producer's byte order (ffn.cuh ffn_mask_byte): column u sits in
+                // byte 4 ((u >> 3) & 3) + ((u >> 5) & 3), bit u & 7; here u = (n0 & 127) + 16 nt + 4 g + r
+                const u32x4 w4 = *(const u32x4*)(Rs + (wave * NSTG + s) * 256 + i * 16);
+                const uint32_t wsel = (nt & 1) ? ((g >> 1) ? w4[3] : w4[2]) : ((g >> 1) ? w4[1] : w4[0]);      // word (2 nt + (g >> 1)) & 3
+                const uint32_t nib = wsel >> (8 * (((n0 >> 6) & 1) * 2 + (nt >> 1)) + 4 * (g & 1));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((nib >> r) & 1u) ? v[r] * p.mask_scale : 0.0f;
             }
             if constexpr (EPI == EPI_ADD) v += load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
             store4((T*)(Ow + so), v[0], v[1], v[2], v[3]);

@@ -34,15 +34,15 @@ template <bool STORE, int ABL, int WV = 8> void run(const char* tag, FfnArgs a, 
 }
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 153600;
-    bf16_t *A, *W1, *W2, *F, *C; float *b1, *b2, *ga, *be, *rstd;
+    bf16_t *A, *W1, *W2, *F, *C; float *b1, *b2, *ga, *be, *rstd; unsigned char* Mb;
     CHECK(hipMalloc(&A, (size_t)M * 256 * 2)); CHECK(hipMalloc(&W1, 1024 * 256 * 2)); CHECK(hipMalloc(&W2, 1024 * 256 * 2));
-    CHECK(hipMalloc(&F, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&C, (size_t)M * 256 * 2));
+    CHECK(hipMalloc(&F, (size_t)M * 1024 * 2)); CHECK(hipMalloc(&Mb, (size_t)M * 128)); CHECK(hipMalloc(&C, (size_t)M * 256 * 2));
     CHECK(hipMalloc(&b1, 4096)); CHECK(hipMalloc(&b2, 1024)); CHECK(hipMalloc(&ga, 1024)); CHECK(hipMalloc(&be, 1024)); CHECK(hipMalloc(&rstd, (size_t)M * 4));
     fill_bf16<<<2048, 256>>>(A, (size_t)M * 256, 1, 1.0f); fill_bf16<<<64, 256>>>(W1, 1024 * 256, 2, 0.1f); fill_bf16<<<64, 256>>>(W2, 1024 * 256, 3, 0.05f);
     fill_f32<<<4, 256>>>(b1, 1024, 4, 0.0f); fill_f32<<<1, 256>>>(b2, 256, 5, 0.0f); fill_f32<<<1, 256>>>(ga, 256, 6, 1.0f); fill_f32<<<1, 256>>>(be, 256, 7, 0.0f);
     CHECK(hipDeviceSynchronize());
     FfnArgs a{};
-    a.A = A; a.lda = 256; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Fo = F; a.ldf = 1024; a.C = C; a.ldc = 256;
+    a.A = A; a.lda = 256; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Fo = F; a.Mb = Mb; a.ldf = 1024; a.C = C; a.ldc = 256;
     a.gamma = ga; a.beta = be; a.rstd = rstd; a.eps = 1e-5f; a.M = M; a.drow_mul = 1;
     FfnArgs ad = a; ad.drop1 = Drop{12345u, 6553u, 1.1111f}; ad.drop2 = Drop{54321u, 6553u, 1.1111f};
     for (int rep = 0; rep < 3; ++rep) {          // A/B of the two block shapes, interleaved (the clocks ramp over the first launches)
