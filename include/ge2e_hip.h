@@ -172,7 +172,9 @@ enum {
     GE2E_K_ATTN_FWD = 8,   /* fused attention forward                                          work = 4*T*T*64 per head */
     GE2E_K_ATTN_BWD = 16,  /* fused attention backward                                         work = 14*T*T*64 per head */
     GE2E_K_LN_BWD = 32,    /* LayerNorm backward                                               work = bytes moved */
-    GE2E_K_FFN = 64        /* chained FFN1 -> ReLU -> FFN2 -> LayerNorm (16-bit modes)         work = 4*M*256*1024 */
+    GE2E_K_FFN = 64,       /* chained FFN1 -> ReLU -> FFN2 -> LayerNorm (16-bit modes)         work = 4*M*256*1024 */
+    GE2E_K_SERIAL = 1 << 30  /* not a class: while set, a backward keeps its weight-gradient kernels on the caller's stream, so the
+                              * timings of every class are those of kernels running ALONE (no overlap with the other stream)   */
 };
 int ge2e_profile_enable(ge2e_handle h, int class_mask);
 int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_work, double* total_bytes,

@@ -16,6 +16,7 @@ PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
 ABI_VERSION = 2
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD, K_FFN = 1, 2, 4, 8, 16, 32, 64
+K_SERIAL = 1 << 30      # with a class bit: the backward keeps its weight gradients on the caller's stream (kernels timed alone)
 
 
 class Config(C.Structure):

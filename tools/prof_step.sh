@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 tag=$1; shift
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline > gpurun_out/prof_$tag.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -o r -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline ${BENCH_ARGS} > gpurun_out/prof_$tag.log 2>&1 || exit 1
 python3 - <<PY
 import csv,glob,json
 f=glob.glob('gpurun_out/prof_$tag/**/*kernel_stats.csv',recursive=True)[0]
