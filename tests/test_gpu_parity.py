@@ -317,6 +317,32 @@ def test_ffn_block_shapes_give_the_same_rows(mods, prec):
     assert torch.equal(e_big[:40], e_small)
 
 
+def test_profile_classes_and_serialised_backward(mods):
+    """ge2e_profile_enable / ge2e_profile_read (bench.py's roofline leg): a class returns its launches, time, algorithmic FLOPs and
+    bytes and is reset by the read; with GE2E_K_SERIAL the backward keeps the weight gradients on the caller's stream -- the same
+    gradients (fp32 sums reorder only) from kernels timed alone."""
+    from speaker_embedding_torch_amd import _lib
+    GE2E, GE2E_Loss = mods
+    m, _, _ = build(GE2E, "bf16", 0.1)
+    m.train()
+    crit = GE2E_Loss().cuda()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(40, 80, 160, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    hnd = m._handle()
+    grads = []
+    for mask in (_lib.K_WGRAD, _lib.K_WGRAD | _lib.K_SERIAL):
+        m.zero_grad(); m._step = 0
+        hnd.profile_enable(mask)
+        crit(m(x), 5).backward()
+        torch.cuda.synchronize()
+        hnd.profile_enable(0)
+        ms, flops, nbytes, launches = hnd.profile_read(_lib.K_WGRAD)
+        assert launches >= 12 and ms > 0 and flops > 0 and nbytes > 0      # 4 per full layer, k|v + q + 3 compact of the last, prenet
+        assert hnd.profile_read(_lib.K_WGRAD)[3] == 0                      # the read reset the class
+        grads.append(torch.cat([p_.grad.flatten() for p_ in m.parameters()]).clone())
+    assert ((grads[0] - grads[1]).norm() / grads[0].norm()).item() < 1e-3
+
+
 # ------------------------------------------------------------------------------------------ full size properties
 @pytest.mark.parametrize("prec,S,P,T", [("bf16", 64, 15, 160), ("fp32", 64, 15, 160),
                                         ("fp16", 256, 10, 180), ("bf16", 256, 10, 180)])
