@@ -81,7 +81,11 @@ int ge2e_max_frames(ge2e_handle h);
  * params: HOST array of ge2e_param_count() DEVICE pointers (fp32), table order
  * pe:     device fp32 [emb, max_position]  -- the `positional_encoding.pe` buffer of the state_dict
  * out_emb:device fp32 [n_utts / samples, emb]  unit-norm d-vectors
- * train:  0 = eval (no dropout, nothing kept); 1 = train (dropout from (seed, step), activations kept in workspace) */
+ * train:  0 = eval (no dropout, nothing kept); 1 = train (dropout from (seed, step), activations kept in workspace);
+ *         eval only, GE2E_FWD_PREPARED (2): the caller states that this workspace still holds the 16-bit weight copies and tables an
+ *         earlier EVAL forward of this handle wrote for the same parameter values, n_utts and frames (an inference loop over one
+ *         checkpoint), behind `stream`: they are not prepared again (3 launches, ~20 us of a 650 us configs[3] forward) */
+#define GE2E_FWD_PREPARED 2
 int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
                          const float* const* params, const float* pe, float* out_emb,
                          void* workspace, size_t workspace_bytes, int train, uint64_t seed, uint64_t step);

@@ -141,7 +141,16 @@ class _EncoderFn(torch.autograd.Function):
         seed, step = module.seed, module._step
         with torch.cuda.device(features.device):      # the library launches on (and creates its side stream for) the CURRENT device
             stream = torch.cuda.current_stream(features.device).cuda_stream
-            hnd.encoder_forward(stream, features, n, t, samples, ptrs, module.positional_encoding.pe, out, ws, train, seed, step)
+            # eval: the 16-bit weight copies in the workspace stay valid while nothing they depend on changed (an inference loop
+            # over one checkpoint): same workspace, shape, stream and parameter storage / version counters
+            prepared = False
+            if not train and not module._poison:
+                pe = module.positional_encoding.pe
+                key = (ws.data_ptr(), n, t, stream, hnd, pe.data_ptr(), pe._version) + tuple((p.data_ptr(), p._version) for p in plist)
+                prepared = module._prepared_key == key
+                module._prepared_key = key
+            hnd.encoder_forward(stream, features, n, t, samples, ptrs, module.positional_encoding.pe, out, ws, train, seed, step,
+                                prepared=prepared)
         if train:
             module._step += 1
         ctx.module, ctx.ws, ctx.train, ctx.token = module, ws, train, token
@@ -209,6 +218,7 @@ class GE2E(torch.nn.Module):
         self._step = 0
         self._handles = {}
         self._ws = {}
+        self._prepared_key = None       # what the eval workspace's weight copies were prepared from (_EncoderFn.forward)
         self._ws_owner = {}
         self._grad_sync = None          # set by distributed.apply_gradient_allreduce
         self._poison = False            # tests: fill every handed-out workspace with NaN bit patterns first

@@ -16,6 +16,7 @@ PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
 ABI_VERSION = 2
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD, K_FFN = 1, 2, 4, 8, 16, 32, 64
+FWD_PREPARED = 2       # ge2e_encoder_forward's `train` argument: eval forward, weight copies already in the workspace
 K_SERIAL = 1 << 30      # with a class bit: the backward keeps its weight gradients on the caller's stream (kernels timed alone)
 
 
@@ -147,12 +148,13 @@ class Handle:
             arr[i] = t.data_ptr()
         return arr
 
-    def encoder_forward(self, stream, mel, n, t, samples, ptrs, pe, out, ws, train, seed, step):
-        """mel: device float32 or float16 [n, mel_dim, t] (the fp16 form is widened by the packing kernel)."""
+    def encoder_forward(self, stream, mel, n, t, samples, ptrs, pe, out, ws, train, seed, step, prepared=False):
+        """mel: device float32 or float16 [n, mel_dim, t] (the fp16 form is widened by the packing kernel).
+        prepared (eval only): the workspace still holds the weight copies of an earlier eval forward (GE2E_FWD_PREPARED)."""
         fn = self.lib.ge2e_encoder_forward_mel16 if str(mel.dtype) == "torch.float16" else self.lib.ge2e_encoder_forward
         self.check(fn(self._h, stream, mel.data_ptr(), n, t, samples, ptrs, pe.data_ptr(),
                       out.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size(),
-                      1 if train else 0, seed, step), "ge2e_encoder_forward")
+                      1 if train else (FWD_PREPARED if prepared else 0), seed, step), "ge2e_encoder_forward")
 
     def encoder_backward(self, stream, mel, n, t, samples, ptrs, d_emb, grads, ws, seed, step, cb=None):
         if cb is None:

@@ -656,11 +656,11 @@ struct SideCtx {
 template <typename T>
 int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, int n, int t, int samples,
                  const float* const* P, const float* pe, float* out_emb, unsigned char* ws, const Layout& L,
-                 bool train, uint64_t seed, uint64_t step) {
+                 bool train, uint64_t seed, uint64_t step, bool prepared = false) {
     const ge2e_config& c = h->cfg;
     const int d = c.emb, R = L.R;
-    // ---- weight preparation (fp32 masters -> T copies, transposed copies for dgrad)
-    {
+    // ---- weight preparation (fp32 masters -> T copies, transposed copies for dgrad); GE2E_FWD_PREPARED: still in the workspace
+    if (!prepared) {
         std::vector<PrepJob> jobs;
         auto add = [&](const float* src, size_t dst, size_t dstT, int rows, int cols, int ldd) {
             PrepJob j{src, ws + dst, (train && dstT != (size_t)-1) ? ws + dstT : nullptr, rows, cols, ldd, 0, (ldd + 31) / 32};
@@ -1105,15 +1105,18 @@ static int encoder_forward_any(ge2e_handle h, void* stream, const void* mel, boo
     if (!mel || !params || !pe || !out_emb) return fail(h, GE2E_EINVAL, "null pointer argument");
     for (size_t i = 0; i < h->params.size(); ++i)
         if (!params[i]) return fail(h, GE2E_EINVAL, "null parameter pointer: " + h->params[i].name);
+    if (train < 0 || train > 2) return fail(h, GE2E_EINVAL, "train: 0, 1 or GE2E_FWD_PREPARED");
+    const bool prepared = train == GE2E_FWD_PREPARED;     // eval with the weight copies already in this workspace
+    train = train == 1;
     const Layout L = build_layout(h->cfg, n_utts, frames, train);
     CK(check_common(h, n_utts, frames, samples, workspace, workspace_bytes, L));
     hipStream_t st = (hipStream_t)stream;
     unsigned char* ws = (unsigned char*)workspace;
     if (h->cfg.precision == GE2E_PREC_BF16)
-        return forward_impl<bf16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+        return forward_impl<bf16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
     if (h->cfg.precision == GE2E_PREC_F16)
-        return forward_impl<f16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
-    return forward_impl<float>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step);
+        return forward_impl<f16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
+    return forward_impl<float>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
 }
 
 int ge2e_encoder_forward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
@@ -1258,6 +1261,7 @@ int ge2e_clip_adamw_step_scaled(ge2e_handle h, void* stream, int count, float* c
 
 void* ge2e_bucket_stream(ge2e_handle h, void* stream) {
     if (!h || !h->overlap || !h->side) return stream;
+    { std::lock_guard<std::mutex> g(h->mu); if (h->prof_mask & GE2E_K_SERIAL) return stream; }   // a serialised backward produces everything on the caller's stream
     return (void*)h->side;
 }
 

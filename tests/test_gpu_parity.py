@@ -301,6 +301,37 @@ def test_multislice_inference_fp32_and_bf16(mods):
         assert e.shape == (8, 256) and rel_l2(e, ref) < tol
 
 
+def test_eval_forward_reuses_prepared_weights_only_while_they_are_valid(mods):
+    """Inference loop over one checkpoint: the second eval forward skips the weight preparation (GE2E_FWD_PREPARED) and returns
+    the same bits; an in-place parameter update (or another shape) invalidates the prepared copies."""
+    GE2E, _ = mods
+    m, _, _ = build(GE2E, "bf16", 0.1)
+    m._poison = False                       # (the NaN-poisoned test workspace would wipe the prepared copies on every call)
+    m.eval()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(40, 80, 64, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    calls = []
+    hnd = m._handle()
+    orig = hnd.encoder_forward
+    hnd.encoder_forward = lambda *a, **k: (calls.append(k.get("prepared", False)), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            e1 = m(x, 5); e2 = m(x, 5)
+            assert calls == [False, True] and torch.equal(e1, e2)
+            m.prenet.weight.mul_(1.5)                                   # in place: same storage, new version
+            e3 = m(x, 5); e4 = m(x, 5)
+            assert calls == [False, True, False, True] and torch.equal(e3, e4) and (e3 - e1).abs().max() > 1e-3
+            m(x[:20].contiguous(), 5)                                   # another shape: another layout
+            assert calls[-1] is False
+    finally:
+        hnd.encoder_forward = orig
+    m2, _, _ = build(GE2E, "bf16", 0.1)
+    m2.eval()
+    with torch.no_grad():
+        m2.prenet.weight.mul_(1.5)
+        assert torch.equal(m2(x, 5), e3)
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_ffn_block_shapes_give_the_same_rows(mods, prec):
     """The chained FFN kernel has two block shapes (ffn.cuh: one 8-wave block or two 4-wave blocks per CU) and the launcher picks one
