@@ -2,7 +2,7 @@
 """Soak test (development tool): many training steps on changing shapes, looking for hangs, faults and non-finite values.
     timeout -k 10 600 python tools/soak.py [--steps 1500] [--shapes 150]
 Phase 1: the benchmark shape, `--steps` consecutive Train_Steps (dropout stream advances every step).
-Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16 and fp32 alternating, fresh NaN-poisoned workspace,
+Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16, fp32 and fp16 in turn, fresh NaN-poisoned workspace,
 one forward + backward + optimizer step each; every gradient must be finite."""
 import argparse, os, sys, time
 import numpy as np
@@ -30,7 +30,7 @@ def main():
             assert np.isfinite(loss.item())
     rng = np.random.default_rng(0)
     for k in range(args.shapes):
-        S = int(rng.integers(2, 9)); P = int(rng.integers(2, 7)); T = int(rng.integers(17, 289)); prec = "bf16" if k % 2 == 0 else "fp32"
+        S = int(rng.integers(2, 9)); P = int(rng.integers(2, 7)); T = int(rng.integers(17, 289)); prec = ("bf16", "fp32", "fp16")[k % 3]
         m = GE2E(hp, precision=prec, seed=k).to(dev); m._poison = True; m.train()
         o = FusedClipAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)
         x = bench.synth_mel(S * P, 80, T, 100 + k, dev)
