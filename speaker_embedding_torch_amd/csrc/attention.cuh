@@ -32,12 +32,38 @@ template <> struct ExpK<bf16_t> { static constexpr float K = 1.4426950408889634f
 template <> struct ExpK<f16_t> : ExpK<bf16_t> {};
 
 namespace attn {
+// LDS image of a [rows][64] head tile, read BOTH by rows (ds_read_b128 operand fragments) and transposed (ds_read_b64_tr_b16):
+//   16-bit modes: plain 128-byte rows, 16-byte chunk c of row r stored at chunk c ^ (r & 7).  Both kinds of read are then free of
+//     bank conflicts: the four 16-lane groups of a ds_read_b128 each cover the 16 sixteen-byte slots of a 256-byte bank row once,
+//     and the 32 eight-byte pieces of a half-wave's transposed read cover it once (rows r0 .. r0 + 7, r0 a multiple of 8).
+//     (A 144-byte padded pitch, used before, made the row reads 2-way: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.41 / 0.43 in
+//     attention backward / forward, profiles/r02_pmc_mfma_lds_per_kernel.csv.)
+//   fp32 mode: 256-byte rows padded by 16 bytes (scalar transposed reads).
 template <typename T> struct Geo {
     static constexpr int ROWB = 64 * (int)sizeof(T);
-    static constexpr int LD = ROWB + 16;               // padded row (tile is read by rows and transposed)
+    static constexpr bool SWZ = sizeof(T) == 2;
+    static constexpr int LD = SWZ ? ROWB : ROWB + 16;
     static constexpr int CPR = ROWB / 16;
     static constexpr int NKG = 64 / Prec<T>::KG;       // k-groups across the head dim
 };
+// byte offset of 16-byte chunk `chunk` of row `row`
+template <typename T> __device__ __forceinline__ int toff(int row, int chunk) {
+    if constexpr (Geo<T>::SWZ) return row * Geo<T>::LD + ((chunk ^ (row & 7)) << 4);
+    else return row * Geo<T>::LD + chunk * 16;
+}
+// transposed fragment of a head tile (rows r0 .. r0 + 31 for 16-bit, columns c0 .. c0 + 15): see frag_tr in common.cuh
+template <typename T> __device__ __forceinline__ u32x4 tile_tr(const unsigned char* tile, int r0, int c0, int lane) {
+    if constexpr (Geo<T>::SWZ) {
+        const int i = lane & 15, g = lane >> 4;
+        const int row = r0 + 4 * g + (i >> 2), bc = (c0 + 4 * (i & 3)) * 2;          // this lane's 8-byte piece: row, byte column
+        const unsigned char* p = tile + toff<T>(row, bc >> 4) + (bc & 8);
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 16 * Geo<T>::LD));      // row + 16: the same swizzle
+        u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{l2.x, l2.y, h2.x, h2.y};
+    } else return frag_tr<T>(tile, Geo<T>::LD, r0, c0, lane);
+}
 
 // cooperative load of `rows` x 64 head slice into a padded tile; rows >= T are zero
 template <typename T>
@@ -48,7 +74,7 @@ __device__ __forceinline__ void load_tile(unsigned char* dst, const unsigned cha
         const int row = id / G::CPR, c = id % G::CPR;
         u32x4 v = u32x4{0, 0, 0, 0};
         if (row < T_) v = *(const u32x4*)(src + (size_t)row * src_ld_bytes + c * 16);
-        *(u32x4*)(dst + row * G::LD + c * 16) = v;
+        *(u32x4*)(dst + toff<T>(row, c)) = v;
     }
 }
 // this lane's row fragments (row `row` of a [.,64] slice) straight from global memory
@@ -67,7 +93,7 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
     f32x4 acc = f32x4{0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < G::NKG; ++k)
-        acc = mma16<T>(lds16(tile + (16 * t + i) * G::LD + (k * 4 + g) * 16), f[k], acc);
+        acc = mma16<T>(lds16(tile + toff<T>(16 * t + i, k * 4 + g)), f[k], acc);
     return acc;
 }
 }  // namespace attn
@@ -131,7 +157,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
             const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // O^T[d = 16dt+4g+r][query] += V^T[d][keys] * P^T[keys][query]
-                oacc[dt] = mma16<T>(frag_tr<T>(Vs, G::LD, gi * KG, dt * 16, lane), pb, oacc[dt]);
+                oacc[dt] = mma16<T>(attn::tile_tr<T>(Vs, gi * KG, dt * 16, lane), pb, oacc[dt]);
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
@@ -235,7 +261,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // dQ^T[d][query] += K^T[d][keys] * dS^T[keys][query]
-                qacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, qacc[dt]);
+                qacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, qacc[dt]);
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
@@ -289,8 +315,8 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                vacc[dt] = mma16<T>(frag_tr<T>(bufB, G::LD, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
-                kacc[dt] = mma16<T>(frag_tr<T>(bufA, G::LD, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
+                vacc[dt] = mma16<T>(attn::tile_tr<T>(bufB, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
+                kacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
             }
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
@@ -377,7 +403,7 @@ __global__ void __launch_bounds__(256) attn_fwd_long_kernel(const AttnArgs p) {
             const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                oacc[dt] = mma16<T>(frag_tr<T>(Vs, G::LD, gi * KG, dt * 16, lane), pb, oacc[dt]);
+                oacc[dt] = mma16<T>(attn::tile_tr<T>(Vs, gi * KG, dt * 16, lane), pb, oacc[dt]);
         }
     }
     const float tot = cross4_sum(lsum);
@@ -460,7 +486,7 @@ __global__ void __launch_bounds__(256) attn_bwd_long_dq_kernel(const AttnArgs p,
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)
-                qacc[dt] = mma16<T>(frag_tr<T>(Ks, G::LD, gi * KG, dt * 16, lane), sb, qacc[dt]);
+                qacc[dt] = mma16<T>(attn::tile_tr<T>(Ks, gi * KG, dt * 16, lane), sb, qacc[dt]);
         }
     }
     if (vq) {
@@ -535,8 +561,8 @@ __global__ void __launch_bounds__(256) attn_bwd_long_dkv_kernel(const AttnArgs p
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                vacc[dt] = mma16<T>(frag_tr<T>(Ds, G::LD, gi * KG, dt * 16, lane), pb, vacc[dt]);
-                kacc[dt] = mma16<T>(frag_tr<T>(Qs, G::LD, gi * KG, dt * 16, lane), sb, kacc[dt]);
+                vacc[dt] = mma16<T>(attn::tile_tr<T>(Ds, gi * KG, dt * 16, lane), pb, vacc[dt]);
+                kacc[dt] = mma16<T>(attn::tile_tr<T>(Qs, gi * KG, dt * 16, lane), sb, kacc[dt]);
             }
         }
     }

@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64 * KT, 3) attn_bwd1_kernel(const AttnArgs p)
     __syncthreads();
     u32x4 kT[4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) kT[dt] = frag_tr<T>(Qs, G::LD, 32 * wave, dt * 16, lane);
+    for (int dt = 0; dt < 4; ++dt) kT[dt] = attn::tile_tr<T>(Qs, 32 * wave, dt * 16, lane);
     __syncthreads();
     attn::load_tile<T>(Qs, qbase, ldq, p.T, TP);
     attn::load_tile<T>(dOs, dobase, ldo, p.T, TP);
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64 * KT, 3) attn_bwd1_kernel(const AttnArgs p)
         const int row = id >> 3, c = id & 7;
         float part = 0.0f;
         if (row < p.T) {
-            const u32x4 a = *(const u32x4*)(dOs + row * G::LD + c * 16);
+            const u32x4 a = *(const u32x4*)(dOs + attn::toff<T>(row, c));
             const u32x4 b = *(const u32x4*)(obase + (size_t)row * ldo + c * 16);
             const T* pa = (const T*)&a; const T* pb = (const T*)&b;
 #pragma unroll
@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(64 * KT, 3) attn_bwd1_kernel(const AttnArgs p)
         }
 #pragma unroll
         for (int dt = 0; dt < ((ABL & 8) ? 0 : 4); ++dt) {
-            const u32x4 ao = frag_tr<T>(dOs, G::LD, 32 * gi, dt * 16, lane);
-            const u32x4 aq = frag_tr<T>(Qs, G::LD, 32 * gi, dt * 16, lane);
+            const u32x4 ao = attn::tile_tr<T>(dOs, 32 * gi, dt * 16, lane);
+            const u32x4 aq = attn::tile_tr<T>(Qs, 32 * gi, dt * 16, lane);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
                 vacc[kt][dt] = mma16<T>(ao, pb[kt], vacc[kt][dt]);      // dV^T += dO^T Pd
