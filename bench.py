@@ -33,7 +33,7 @@ sys.path.insert(0, REPO)
 from speaker_embedding_torch_amd import _lib  # noqa: E402
 from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters  # noqa: E402
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
-from speaker_embedding_torch_amd.Optim import FusedClipAdamW  # noqa: E402
+from speaker_embedding_torch_amd.Optim import FusedClipAdamW, GradScaler  # noqa: E402
 
 PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
 DTYPE_NAME = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}
@@ -203,6 +203,7 @@ def main():
     optimizer = FusedClipAdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,
                                betas=(hp.Train.ADAM.Beta1, hp.Train.ADAM.Beta2), eps=hp.Train.ADAM.Epsilon,
                                max_norm=hp.Train.Gradient_Norm)      # clip_grad_norm_ + AdamW, as Train.py:154-162
+    scaler = GradScaler(enabled=args.precision == "fp16")        # Train.py:134: float16 runs under dynamic loss scaling
     model.train()
     batches = [synth_mel(S * P, mel, T, 1234 + rank + 1000 * i, dev) for i in range(2)]   # resident in HBM
     if args.mode == "infer":      # secondary figure (not BASELINE.json's metric): multi-slice d-vector extraction
@@ -256,8 +257,10 @@ def main():
         emb = model(batches[i & 1] if host is None else fetch(i))
         loss = criterion(emb, P)
         optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
+        scaler.scale(loss).backward()
+        scaler.unscale_(optimizer)
+        scaler.step(optimizer)               # (un)scale + inf check + clip + AdamW (+ scale update), fused: Trainer.Train_Step's calls
+        scaler.update()
         return loss
 
     def fence():
@@ -336,14 +339,15 @@ def main():
                                      "avg_launch_us": round(alone[2], 2)}
     if rank == 0:
         out = {
-            "metric": "utterances/sec (64spk x 15utt, T=160, 80-mel) training step",
+            "metric": f"utterances/sec ({S}spk x {P}utt, T={T}, {mel}-mel) training step",
             "value": round(S * P * world * args.steps / dt, 1), "unit": "utterances/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_NAME[args.precision], "data": "synthetic",
             "input": args.input + ("+prefetch" if (args.prefetch and args.input != "resident") else ""),
             "config": {"workload": f"{S} spk x {P} utt x {T} fr x {mel} mel per GPU, full Train_Step "
-                                   f"(fwd+GE2E loss+bwd+clip+AdamW), dropout 0.1, random-init weights",
+                                   f"(fwd+GE2E loss+bwd+clip+AdamW{'+loss scaling' if scaler.is_enabled() else ''}), "
+                                   f"dropout {hp.GE2E.Transformer.Dropout_Rate:g}, random-init weights",
                        "per_gpu_batch": S * P, "global_batch": S * P * world,
                        "parallelism": f"dp{world}" if world > 1 else "single"},
             "final_loss": round(final_loss, 5),

@@ -11,7 +11,9 @@
  *
  * Conventions: plain pointers and sizes only; all device buffers are allocated and owned by the caller
  * (PyTorch); every call is asynchronous on the hipStream_t it is handed and never synchronises the device;
- * the library holds no thread-local state (backward is invoked from the autograd thread).
+ * no state is kept per thread ACROSS calls (backward is invoked from the autograd thread): the one thread-local the library
+ * has lives strictly inside a ge2e_encoder_backward* call, between two of its own launches, and is empty whenever the bucket
+ * callback runs -- the callback may therefore call back into the library on any stream.
  * Every function returns 0 on success, a negative GE2E_E* code for invalid arguments, or a positive
  * hipError_t passed through; ge2e_last_error() gives the text.  No C++ exception crosses this boundary.
  */

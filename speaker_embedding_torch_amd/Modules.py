@@ -153,6 +153,7 @@ class _EncoderFn(torch.autograd.Function):
                                 prepared=prepared)
         if train:
             module._step += 1
+            module._prepared_key = None     # a training step follows: whatever updates the weights may not bump their version counters
         ctx.module, ctx.ws, ctx.train, ctx.token = module, ws, train, token
         ctx.dims = (n, t, samples, seed, step)
         ctx.save_for_backward(features, *params)

@@ -101,6 +101,10 @@ class FusedClipAdamW(torch.optim.AdamW):
     def step(self, closure=None, scaler=None):
         if closure is not None:
             raise RuntimeError("FusedClipAdamW does not take a closure")
+        if scaler is not None and scaler.is_enabled() and sum(1 for g in self.param_groups if any(p.grad is not None for p in g["params"])) > 1:
+            # the scaled step ends with ONE scale / growth-tracker / steps-taken update: with several groups that update would run once
+            # per group, and an inf in a later group could not undo an earlier group's update (torch's GradScaler skips the whole step)
+            raise RuntimeError("FusedClipAdamW: loss scaling supports one param_group (the reference's optimizer has one, Train.py:122-127)")
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.grad is not None]
             if not ps:
@@ -143,7 +147,16 @@ class FusedClipAdamW(torch.optim.AdamW):
                                               float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step)
                     for st in states:
                         st["step"] = torch.tensor(float(step))
+            # The kernels wrote the parameters through raw pointers: autograd's version counters did not see it.  Bump them so that
+            # anything keyed on `p._version` (Modules._EncoderFn's prepared-weights key, saved-tensor checks) notices the update.
+            for p in ps:
+                torch._C._increment_version(p)
         return None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._scaled_steps = None    # re-seed the device-side step counter from the loaded 'step' at the next scaled step
+        self._tables = None
 
     def state_dict(self):
         """torch.optim.AdamW's layout.  Under device-side loss scaling the number of steps actually taken lives on the device

@@ -110,6 +110,9 @@ class Trainer:
             optimizer=self.optimizer, gamma=self.hp.Train.Learning_Rate.Decay, last_epoch=-1)
         # Train.py:134: GradScaler(enabled=Use_Mixed_Precision).  Only float16 needs it (bfloat16 keeps fp32's exponent range)
         self.scaler = GradScaler(enabled=self.model.precision == "fp16")
+        # `Use_Mixed_Precision: true` without the optional key `Mixed_Precision_Dtype` means float16 + dynamic loss scaling (what
+        # autocast is in the reference); say which mode runs, so a resumed run that changed mode is visible in the log
+        logging.info("Arithmetic mode: {}{}.".format(self.model.precision, " + dynamic loss scaling" if self.scaler.is_enabled() else ""))
 
     # -------------------------------------------------------------------------------------- steps
     def Train_Step(self, features):
@@ -243,6 +246,8 @@ class Trainer:
         hp_copy = os.path.join(self.hp.Checkpoint_Path, "Hyper_Parameters.yaml").replace("\\", "/")
         if self.gpu_id == 0 and not os.path.exists(hp_copy):
             os.makedirs(self.hp.Checkpoint_Path, exist_ok=True)
+            if getattr(self.hp, "Use_Mixed_Precision", False) and not hasattr(self.hp, "Mixed_Precision_Dtype"):
+                self.hp.Mixed_Precision_Dtype = self.model.precision      # the copy records the RESOLVED 16-bit mode (a resume keeps it)
             with open(hp_copy, "w") as f:
                 yaml.dump(self.hp, f)
         if self.gpu_id == 0:

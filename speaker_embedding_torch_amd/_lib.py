@@ -115,8 +115,10 @@ class Handle:
         self._h = C.c_void_p()
         rc = self.lib.ge2e_create(C.byref(self.cfg), C.byref(self._h))
         if rc != 0:
-            raise RuntimeError(f"ge2e_create failed ({rc}): unsupported configuration "
-                               f"(emb must be 256 with 64-dim heads, ffn a multiple of 128)")
+            raise RuntimeError(f"ge2e_create failed ({rc}): unsupported configuration -- the kernels are laid out for "
+                               f"GE2E.Embedding_Size 256 with 64-wide heads (GE2E.Transformer.Head = 4, the reference's shipped "
+                               f"Hyper_Parameters.yaml:11,17), 1..8 layers, Mel_Dim <= 128, ffn a multiple of 128; got emb={emb}, "
+                               f"heads={heads}, layers={layers}, mel_dim={mel_dim}, ffn={ffn}")
         n = self.lib.ge2e_param_count(self._h)
         self.param_names = [self.lib.ge2e_param_name(self._h, i).decode() for i in range(n)]
         self.param_numel = [self.lib.ge2e_param_numel(self._h, i) for i in range(n)]

@@ -236,8 +236,23 @@ struct ProfScope {
 // Armed launches (SideCtx::arm): while a fence event is armed for a stream, every kernel launched on that stream carries it as its
 // completion ("stop") event, so the event completes with the LAST such kernel and no separate marker packet follows it in the
 // queue.  A recorded marker costs the main chain ~6 us of idle queue per fence (rocprofv3 timeline); a bound event costs nothing.
+// tl_armed is thread-local (a backward runs on ONE host thread) and is only ever non-empty between SideCtx::arm() and the
+// SideCtx::fork() that follows it inside backward_body -- never across a C-ABI call and never while a bucket callback runs
+// (callbacks are invoked after a fork(), which clears it), so a re-entrant call from the callback sees it empty.
 struct ArmedEvent { hipEvent_t ev = nullptr; hipStream_t on_stream = nullptr; int launches = 0; };
 static thread_local ArmedEvent tl_armed;
+
+// tests only (GE2E_DEBUG_SIDE_DELAY_US): holds the weight-gradient stream back after every fork so that the main chain reaches
+// its "wait for the reader of this scratch buffer" fences while the reader really is still running.  100 MHz realtime ticks;
+// the loop ends when the time is up, whatever else the chip does.
+__global__ void debug_delay_kernel(unsigned ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(64);
+}
+inline int debug_side_delay_us() {
+    static const int us = [] { const char* e = getenv("GE2E_DEBUG_SIDE_DELAY_US"); const int v = e ? atoi(e) : 0; return std::max(0, std::min(v, 5000)); }();
+    return us;
+}
 #define GE2E_LAUNCH(h, kern, grid, block, smem, st, ...)                                                   \
     do {                                                                                                    \
         static std::atomic<size_t> attr_max{(size_t)48 * 1024};                                             \
@@ -626,10 +641,11 @@ struct SideCtx {
         tl_armed = ArmedEvent{};
         if (a.ev && a.launches > 0) {       // bound to the last kernel before this point
             if (hipStreamWaitEvent(side, a.ev, 0) != hipSuccess) err = 1;
-            return;
+        } else {
+            hipEvent_t e = a.ev ? a.ev : ev();  // (an armed event no kernel took is still unrecorded: use it here)
+            if (!e || hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) err = 1;
         }
-        hipEvent_t e = a.ev ? a.ev : ev();  // (an armed event no kernel took is still unrecorded: use it here)
-        if (!e || hipEventRecord(e, main_st) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) err = 1;
+        if (const int us = debug_side_delay_us()) hipLaunchKernelGGL(debug_delay_kernel, dim3(1), dim3(64), 0, side, (unsigned)(us * 100));
     }
     hipEvent_t mark() {                     // event after everything enqueued on side so far
         if (!on) return nullptr;

@@ -288,6 +288,83 @@ def test_fp32_other_layer_counts(mods, layers):
         assert rel_l2(prm.grad.cpu().numpy(), grads_ref[name]) < tol, name
 
 
+_DEPTH_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {tests!r})
+import test_gpu_parity as tp
+from oracle import ge2e_oracle as O
+from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+m, params, pe = tp.build(GE2E, {prec!r}, 0.1, layers={layers})          # NaN-poisoned workspace
+m.train()
+x = torch.from_numpy(O.formula_mel(41, {n}, 80, {t}, logmel=True)).cuda()
+out = {{}}
+for rep in range(2):                                                     # twice: the second backward recycles the first one's event set
+    m.zero_grad(); m._step = 0
+    emb = m(x); loss = GE2E_Loss().cuda()(emb, 4); (loss * {scale}).backward()
+    torch.cuda.synchronize()
+    out["emb%d" % rep] = emb.detach().cpu().numpy(); out["loss%d" % rep] = np.float32(loss.item())
+    for k, p in m.named_parameters():
+        out["g%d_" % rep + k] = p.grad.cpu().numpy() / {scale}
+np.savez({out!r}, **out)
+"""
+
+
+@pytest.mark.parametrize("prec,layers", [("fp32", 4), ("bf16", 5), ("fp16", 4)])
+def test_deep_stacks_reuse_backward_scratch_behind_waits(mods, tmp_path, prec, layers):
+    """Num_Layers (reference Hyper_Parameters.yaml:16) above 3: the backward's scratch sets alias between layers (Layout: set
+    l % 2, dQKV l % 3) and the main chain must WAIT for the weight-gradient stream's reader of a buffer before overwriting it
+    (`sc.wait(g_set1 / g_dF / g_set2 / g_dQKV)` in backward_body).  A full train step against the oracle on a NaN-poisoned
+    workspace, three ways: as shipped; with the weight-gradient stream held back 400 us after every fork
+    (GE2E_DEBUG_SIDE_DELAY_US: a missing wait then overwrites an operand the weight gradient has not read yet) and one
+    wgrad_ks block per CU (GE2E_WGRAD_KS_BLOCKS=256); and serialised on one stream (GE2E_NO_OVERLAP).  All three must agree
+    with each other to fp32 summation order and with the oracle within the mode's bound."""
+    import subprocess, sys as _sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n, t = 24, 128
+    scale = 1024.0 if prec == "fp16" else 1.0
+    res = {}
+    for tag, extra in (("shipped", {}), ("delayed", {"GE2E_DEBUG_SIDE_DELAY_US": "400", "GE2E_WGRAD_KS_BLOCKS": "256"}),
+                       ("serial", {"GE2E_NO_OVERLAP": "1"})):
+        out = str(tmp_path / f"{tag}.npz")
+        code = _DEPTH_SCRIPT.format(repo=repo, tests=os.path.join(repo, "tests"), out=out, prec=prec, layers=layers, n=n, t=t, scale=scale)
+        r = subprocess.run([_sys.executable, "-c", code], env=dict(os.environ, **extra), cwd=repo, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = dict(np.load(out))
+    params = O.formula_params(layers=layers)
+    from speaker_embedding_torch_amd.Modules import Positional_Encoding
+    pe = Positional_Encoding(1024, 256, 0.1).pe[0].t().contiguous().numpy()
+    x_np = O.formula_mel(41, n, 80, t, logmel=True)
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=0.1, p_tf=0.1, pe=pe)
+    loss_ref, lc = O.loss_forward(emb_ref, 4)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    base = res["serial"]
+    for tag in ("shipped", "delayed"):
+        a = res[tag]
+        for rep in (0, 1):
+            assert np.array_equal(a[f"emb{rep}"], base["emb0"]), tag                # forward: no atomics, bitwise
+            for k in grads_ref:
+                g, r = a[f"g{rep}_{k}"], base["g0_" + k]
+                assert np.isfinite(g).all(), (tag, k)
+                assert rel_l2(g, r) < 1e-4, (tag, rep, k, rel_l2(g, r))               # same kernels, fp32 sums in another order
+    e = base["emb0"]
+    if prec == "fp32":
+        assert rel_l2(e, emb_ref) < 1e-4 and abs(float(base["loss0"]) - float(loss_ref)) < 1e-5
+        tol = 2e-3 if _relu_margin_ok(c) else 0.2
+        for k in grads_ref:
+            assert rel_l2(base["g0_" + k], grads_ref[k]) < tol, k
+    else:
+        # 16-bit storage error grows with depth (profiles/r02_precision_taps.md: ~0.4 roundoffs per stored tensor): bounds = the
+        # 3-layer bounds x 2 for bf16; float16 keeps its own
+        etol, gtol, ctol = (4e-2, 0.3, 0.97) if prec == "bf16" else (5e-3, 8e-2, 0.997)
+        assert rel_l2(e, emb_ref) < etol
+        for k in grads_ref:
+            g, r = base["g0_" + k].ravel().astype(np.float64), grads_ref[k].ravel().astype(np.float64)
+            if g.size == 1:
+                continue
+            cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            assert cos > ctol and rel_l2(g, r) < gtol, (k, cos, rel_l2(g, r))
+
+
 def test_multislice_inference_fp32_and_bf16(mods):
     """config 4 shape family: `samples` overlapping slices averaged BEFORE projection (Modules.py:55)."""
     GE2E, _ = mods
@@ -330,6 +407,75 @@ def test_eval_forward_reuses_prepared_weights_only_while_they_are_valid(mods):
     with torch.no_grad():
         m2.prenet.weight.mul_(1.5)
         assert torch.equal(m2(x, 5), e3)
+
+
+def test_eval_after_fused_optimizer_step_sees_the_new_weights(mods, tmp_path):
+    """The fused optimizer updates the parameters through raw pointers inside libge2e_hip.so.  An eval forward after Train_Steps
+    (Trainer.Evaluation_Step on a fixed validation batch: same shape, workspace, stream) must not reuse weight copies prepared
+    before the update: eval(x) -> Train_Step x 2 -> eval(x) == a fresh model loaded with the updated state_dict."""
+    from speaker_embedding_torch_amd.Optim import FusedClipAdamW
+    GE2E, GE2E_Loss = mods
+    m, _, _ = build(GE2E, "bf16", 0.1)
+    m._poison = False
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = (torch.randn(40, 80, 64, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    opt = FusedClipAdamW(m.parameters(), lr=1e-2, max_norm=1.0)
+    crit = GE2E_Loss().cuda()
+    calls = []
+    hnd = m._handle()
+    orig = hnd.encoder_forward
+    hnd.encoder_forward = lambda *a, **k: (calls.append(k.get("prepared", False)), orig(*a, **k))[1]
+    try:
+        m.eval()
+        with torch.no_grad():
+            e_before = m(x); m(x)
+        assert calls == [False, True]
+        versions = [p._version for p in m.parameters()]
+        m.train()
+        for _ in range(2):
+            loss = crit(m(x), 5); opt.zero_grad(); loss.backward(); opt.step()
+        assert all(p._version > v for p, v in zip(m.parameters(), versions))    # the raw-pointer update is visible to autograd
+        m.eval()
+        with torch.no_grad():
+            e_after = m(x)
+        assert calls[-1] is False                                               # re-prepared
+    finally:
+        hnd.encoder_forward = orig
+    assert (e_after - e_before).abs().max() > 1e-3
+    fresh, _, _ = build(GE2E, "bf16", 0.1)
+    fresh.load_state_dict(m.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        assert torch.equal(fresh(x), e_after)
+
+
+def test_full_size_multislice_inference(mods, golden):
+    """BASELINE.json configs[3] at full size: Inference.py's multi-slice d-vector extraction, 256 utterances x 5 slices x 64
+    frames, embed only (reference Inference.py:157-159: model(mels, Samples) in eval / no_grad; Modules.py:55 averages the slices
+    BEFORE the projection).  Size-independent properties + an oracle check of the first 16 utterances (80 slices), bf16 / fp16 /
+    fp32; the golden G5 vector (the reference's own output for 4 x 5 slices) sits in the same batch family and is checked in
+    test_fp32_eval_matches_reference_goldens."""
+    GE2E, _ = mods
+    U, S5, T = 256, 5, 64
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = (torch.randn(U * S5, 80, T, device="cuda", generator=g) * 2 - 5).clamp_(-11.5129, 2.0)
+    for prec, tol in (("bf16", 2e-2), ("fp16", 3e-3), ("fp32", 1e-4)):
+        m, params, pe = build(GE2E, prec, 0.1)
+        m.eval()
+        with torch.no_grad():
+            e = m(x, S5)
+            e2 = m(x, S5)
+            perm = torch.randperm(U, device="cuda", generator=g)
+            xp = x.view(U, S5, 80, T)[perm].reshape(U * S5, 80, T).contiguous()
+            ep = m(xp, S5)
+            e_sub = m(x[: 16 * S5].contiguous(), S5)
+        assert e.shape == (U, 256) and torch.isfinite(e).all()
+        assert (e.norm(dim=1) - 1).abs().max() < 1e-5
+        assert torch.equal(e, e2)                                              # no atomics in the forward: bitwise
+        assert (ep - e[perm]).abs().max() < 1e-6                               # an utterance's d-vector does not depend on its place
+        assert (e_sub - e[:16]).abs().max() < 1e-6                             # ... nor on the batch size
+        ref, _ = O.encoder_forward(params, x[: 16 * S5].cpu().numpy(), samples=S5, pe=pe)
+        assert rel_l2(e[:16].cpu().numpy(), ref) < tol, prec
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])

@@ -162,6 +162,19 @@ def test_two_rank_data_parallel_gradient_mean(tmp_path):
         crit(model(torch.from_numpy(O.formula_mel(20 + r, 8, 80, 48, logmel=True)).cuda()), 4).backward()
         acc = acc + torch.cat([p.grad.flatten() for p in model.parameters()]).cpu()
     assert rel_l2(g0.numpy(), (acc / 2).numpy()) < 1e-4
+    # ... and the oracle (reference distributed.py:88-112: gradients summed over ranks / world): mean of O.encoder_backward over
+    # the two rank batches with the broadcast weights
+    names = [k for k, _ in model.named_parameters()]
+    params = {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}
+    pe = model.positional_encoding.pe[0].t().contiguous().cpu().numpy()
+    mean_ref = None
+    for r in range(2):
+        emb_ref, c = O.encoder_forward(params, O.formula_mel(20 + r, 8, 80, 48, logmel=True), train=True, seed=7, step=0, p_pe=0.0, p_tf=0.0, pe=pe)
+        _, lc = O.loss_forward(emb_ref, 4)
+        gr = O.encoder_backward(params, c, O.loss_backward(lc))
+        flat = np.concatenate([gr[k].ravel() for k in names])
+        mean_ref = flat / 2 if mean_ref is None else mean_ref + flat / 2
+    assert rel_l2(g0.numpy(), mean_ref) < 2e-3
     total = g0.numel()
     assert len(b0) == 5 and sum(c for _, c in b0) == total         # tail, 3 layers, prenet: disjoint cover
     assert b0[0][0] + b0[0][1] == total and b0[-1][0] == 0
@@ -209,10 +222,19 @@ def test_global_batch_loss_equals_single_process_on_the_concatenated_batch(tmp_p
     loss = GE2E_Loss().cuda()(model(x_all), 3)
     loss.backward()
     ref = torch.cat([p.grad.flatten() for p in model.parameters()]).cpu()
+    # the oracle on the concatenated 4-speaker batch
+    names = [k for k, _ in model.named_parameters()]
+    params = {k: v.detach().cpu().numpy() for k, v in model.named_parameters()}
+    pe = model.positional_encoding.pe[0].t().contiguous().cpu().numpy()
+    emb_ref, c = O.encoder_forward(params, O.formula_mel(31, 12, 80, 48, logmel=True), train=True, seed=7, step=0, p_pe=0.0, p_tf=0.0, pe=pe)
+    loss_ref, lc = O.loss_forward(emb_ref, 3)
+    gr = O.encoder_backward(params, c, O.loss_backward(lc))
+    ora = np.concatenate([gr[k].ravel() for k in names])
     for rank in (0, 1):
         l, g = res[rank]
-        assert abs(l - loss.item()) < 1e-5
+        assert abs(l - loss.item()) < 1e-5 and abs(l - float(loss_ref)) < 1e-5
         assert rel_l2(g.numpy(), ref.numpy()) < 1e-4
+        assert rel_l2(g.numpy(), ora) < 2e-3
     assert torch.equal(res[0][1], res[1][1])
 
 
