@@ -149,8 +149,7 @@ class FusedClipAdamW(torch.optim.AdamW):
                         st["step"] = torch.tensor(float(step))
             # The kernels wrote the parameters through raw pointers: autograd's version counters did not see it.  Bump them so that
             # anything keyed on `p._version` (Modules._EncoderFn's prepared-weights key, saved-tensor checks) notices the update.
-            for p in ps:
-                torch._C._increment_version(p)
+            torch._C._increment_version(ps)
         return None
 
     def load_state_dict(self, state_dict):
