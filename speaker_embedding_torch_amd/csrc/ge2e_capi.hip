@@ -433,19 +433,28 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             // main chain on the other stream: the two then share the chip in SPACE instead of taking turns (measured, step time:
             // 256 blocks 4.29 ms, 192 4.19, 160 4.16, 128 4.20, 96 4.26).  GE2E_WGRAD_KS_BLOCKS overrides.
             static const int blocks_cap = [] { const char* e = getenv("GE2E_WGRAD_KS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : WK_DEFAULT_BLOCKS; }();
-            int splits = std::min(std::min(WK_MAX_BLOCKS, blocks_cap), h->num_cus) / (tn * tk);
+            const int ntile = tn * tk;
+            int splits = std::min(std::min(WK_MAX_BLOCKS, blocks_cap), h->num_cus) / ntile;
+            // whole XCD rounds: the kernel deals row slices to the 8 XCDs (wgrad_ks.cuh), so a multiple of 8 leaves no XCD a block short
+            if (splits >= 8) splits = std::min((splits + 4) / 8 * 8, WK_MAX_BLOCKS / ntile / 8 * 8);
             splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
             const int sps = (stages + splits - 1) / splits;
             splits = (stages + sps - 1) / sps;
             WgradKsArgs k{};
             k.Y = a.Y; k.ldy = a.ldy; k.X = a.X; k.ldx = a.ldx; k.part = part; k.db = a.db; k.R32 = R32; k.rows_per_split = sps * 32;
-            k.tiles_n = tn; k.tiles_k = tk;
+            k.tiles_n = tn; k.tiles_k = tk; k.splits = splits;
+            static const bool flat = getenv("GE2E_WGRAD_KS_FLAT") != nullptr;
+            k.flat_order = flat ? 1 : 0;
+            // one scope around the product AND its reduce pass: `roofline.kernel` names both, and the class time is then what rocprof
+            // shows for the two rows together
             {
                 ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R32 * (double)a.N * a.K, (double)R32 * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
                 auto kern = wgrad_ks_kernel<T>;
-                GE2E_LAUNCH(h, kern, dim3(tn * tk * splits), dim3(512), wgrad_ks_smem(), st, k);
+                GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
+                // split groups: ~256 reduce blocks whatever the tile count (a single-tile product used to sum its 160 partials in 64 blocks)
+                const int sgroups = std::max(1, std::min(splits, 256 / (ntile * 32)));
+                GE2E_LAUNCH(h, wgrad_ks_reduce_kernel, dim3(ntile * 32, sgroups), dim3(512), 0, st, (const float*)part, a.dW, a.ldw, splits, tn, tk);
             }
-            GE2E_LAUNCH(h, wgrad_ks_reduce_kernel, dim3(tn * tk * 64), dim3(256), 0, st, (const float*)part, a.dW, a.ldw, splits, tn, tk);
             if (R32 == a.R) return 0;
             WgradArgs tail = a;                                          // < 32 rows left: the tiled kernel adds them atomically
             tail.Y = (const unsigned char*)a.Y + (size_t)R32 * a.ldy * sizeof(T);

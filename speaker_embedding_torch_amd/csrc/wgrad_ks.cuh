@@ -15,6 +15,11 @@
 //   * the fp32 tile leaves as PLAIN 16-byte stores in fragment order into a partial slab (split x tile x 256 KB; coalesced,
 //     no atomics: 64 MB of float atomics per launch would take 50 us at the chip's 1.3 TB/s atomic rate), and
 //     wgrad_ks_reduce_kernel sums the splits and un-permutes into dW;
+//   * block -> (tile, row slice) is XCD-aware: the tiles of ONE row slice share their narrow operand panel (dW2: the 256 columns
+//     of dM, dW1 / in_proj: the 256 columns of h), so they sit on ONE XCD (blocks b and b + 8 share an XCD under round-robin
+//     dispatch; speed only) at neighbouring positions and stream that panel through the XCD's L2 together: it comes from HBM once
+//     per row slice instead of once per tile (round 2 put them on consecutive block ids = different XCDs: PMC 342 MB fetched
+//     per launch for 230 MB algorithmic);
 //   * the bias gradient rides along as one extra MFMA per n-tile against a fragment of ones (k-tile-0 blocks only).
 // Rows beyond the last multiple of 32 and the small shapes (one 256 x 256 tile or less, the prenet's K = 80) stay on the
 // 128 x 128 kernel.  (A variant with ONE wave per SIMD, 128 x 128 accumulators per wave in the accumulator file and double-
@@ -39,6 +44,8 @@ struct WgradKsArgs {
     int R32;                     // rows handled here (multiple of 32)
     int rows_per_split;          // multiple of 32
     int tiles_n, tiles_k;        // 256 x 256 tiles along N and K
+    int splits;                  // row slices; grid = 8 * tiles * ceil(splits / 8) blocks, the surplus ones exit at once
+    int flat_order;              // ablation (GE2E_WGRAD_KS_FLAT=1): round 2's order, tile = b % tiles -- the tiles of a slice on different XCDs
 };
 
 template <typename T> __device__ __forceinline__ constexpr unsigned wk_one2();
@@ -60,7 +67,7 @@ __device__ __forceinline__ void wk_lds_retire(u32x4* f) {      // all 12 fragmen
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// grid = tiles_n * tiles_k * splits blocks (<= one per CU) of 512 threads
+// grid = 8 * tiles_n * tiles_k * ceil(splits / 8) blocks (<= one per CU) of 512 threads
 template <typename T>
 __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage modes");
@@ -72,7 +79,11 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     const bool lag = wave >= 4;
     const int i = lane & 15, g = lane >> 4;
     const int ntile = p.tiles_n * p.tiles_k;
-    const int tile = blockIdx.x % ntile, split = blockIdx.x / ntile;
+    // XCD x = b & 7 holds row slices x, x + 8, ...; position j = b >> 3 inside the XCD walks the tiles of a slice first
+    const int xj = blockIdx.x >> 3;
+    const int tile = p.flat_order ? (int)blockIdx.x % ntile : xj % ntile;
+    const int split = p.flat_order ? (int)blockIdx.x / ntile : (xj / ntile) * 8 + ((int)blockIdx.x & 7);
+    if (split >= p.splits) return;                          // (whole block, before any barrier)
     const int n0 = (tile % p.tiles_n) * 256, k0 = (tile / p.tiles_n) * 256;
     const int rbeg = split * p.rows_per_split;
     const int rend = min(p.R32, rbeg + p.rows_per_split);
@@ -193,25 +204,40 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     }
 }
 
-// dW[n][k] += sum over splits of the partial tiles.  One thread per 16-byte fragment element: grid = tiles * 64 blocks of 256 threads.
-__global__ void __launch_bounds__(256) wgrad_ks_reduce_kernel(const float* part, float* dW, int ldw, int splits, int tiles_n, int tiles_k) {
+// dW[n][k] += sum over splits of the partial tiles.  A (tile, wave, mt) group of the fragment order -- 16 rows n x 128 columns k --
+// is ONE contiguous 8 KB piece of every split's partial tile: a 512-thread block sums that piece over its share of the splits
+// (16-byte loads, 8 in flight per thread), turns it through LDS and adds it to dW as whole 512-byte row segments, 256 contiguous
+// bytes per wave instruction (the full-rate atomic shape; dW is at most 1 MB and lives in the caches, so these few MB of
+// atomics cost nothing next to the partial reads).  grid = (tiles * 32, split groups).
+// (Round 2: one thread per fragment element summed ALL splits serially and read-modify-wrote dW in 64-byte pieces: 20-60 us.)
+__global__ void __launch_bounds__(512) wgrad_ks_reduce_kernel(const float* part, float* dW, int ldw, int splits, int tiles_n, int tiles_k) {
+    __shared__ float tr[16][132];
     const int ntile = tiles_n * tiles_k;
-    const int tile = blockIdx.x / 64, e = (blockIdx.x % 64) * 256 + threadIdx.x;     // e = ((wave * 4 + mt) * 8 + nt) * 64 + lane
-    const f32x4* src = (const f32x4*)(part + (size_t)tile * WK_TILE_FLOATS) + e;
+    const int tile = blockIdx.x >> 5, grp = blockIdx.x & 31;          // grp = wave * 4 + mt
+    const int t = threadIdx.x, lane = t & 63, nt = t >> 6;
+    const f32x4* src = (const f32x4*)(part + (size_t)tile * WK_TILE_FLOATS) + grp * 512 + t;
     const size_t stride = (size_t)ntile * (WK_TILE_FLOATS / 4);
     f32x4 s0 = f32x4{0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
-    int sp = 0;
-    for (; sp + 4 <= splits; sp += 4) {
-        s0 += src[(size_t)sp * stride]; s1 += src[(size_t)(sp + 1) * stride];
-        s2 += src[(size_t)(sp + 2) * stride]; s3 += src[(size_t)(sp + 3) * stride];
+    int sp = blockIdx.y;
+    const int sg = gridDim.y;
+    for (; sp + 3 * sg < splits; sp += 4 * sg) {
+        const f32x4 a = __builtin_nontemporal_load(src + (size_t)sp * stride), b = __builtin_nontemporal_load(src + (size_t)(sp + sg) * stride);
+        const f32x4 c = __builtin_nontemporal_load(src + (size_t)(sp + 2 * sg) * stride), d = __builtin_nontemporal_load(src + (size_t)(sp + 3 * sg) * stride);
+        s0 += a; s1 += b; s2 += c; s3 += d;
     }
-    for (; sp < splits; ++sp) s0 += src[(size_t)sp * stride];
+    for (; sp < splits; sp += sg) s0 += __builtin_nontemporal_load(src + (size_t)sp * stride);
     const f32x4 v = (s0 + s1) + (s2 + s3);
-    const int lane = e & 63, nt = (e >> 6) & 7, mt = (e >> 9) & 3, wave = e >> 11;
-    const int i = lane & 15, g = lane >> 4, wn = wave & 3, wk = wave >> 2;
-    const int n = (tile % tiles_n) * 256 + 64 * wn + 16 * mt + 4 * g, k = (tile / tiles_n) * 256 + 128 * wk + 16 * nt + i;
+    const int i = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dW[(size_t)(n + r) * ldw + k] += v[r];
+    for (int r = 0; r < 4; ++r) tr[4 * g + r][16 * nt + i] = v[r];   // v[r] = dW[n0 + 4g + r][k0 + 16 nt + i]
+    __syncthreads();
+    const int wave = grp >> 2, mt = grp & 3, wn = wave & 3, wk = wave >> 2;
+    const int n0 = (tile % tiles_n) * 256 + 64 * wn + 16 * mt, k0 = (tile / tiles_n) * 256 + 128 * wk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = q * 512 + t, row = e >> 7, col = e & 127;
+        atomicAdd(dW + (size_t)(n0 + row) * ldw + k0 + col, tr[row][col]);
+    }
 }
 
 }  // namespace ge2e

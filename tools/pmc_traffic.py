@@ -14,7 +14,10 @@ from collections import defaultdict
 CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
     "gemm": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_ws_lnbwd_kernel" in n) and not is_ln(n),
     "gemm_ln": lambda n: ("gemm_nt_kernel" in n or "gemm_ws_kernel" in n or "gemm_kl_kernel" in n) and is_ln(n),
-    "wgrad": lambda n: "wgrad_kernel" in n or "wgrad_ks_kernel" in n,          # what bench.py's wgrad class brackets (not the reduce pass)
+    # what bench.py's wgrad class brackets: one scope per product = wgrad_ks_kernel + its reduce pass, or one wgrad_kernel launch
+    # (NOT tail_wgrad_kernel, which "wgrad_kernel" in n would also match).  Per LAUNCH of the class = per product: the reduce
+    # pass's bytes are added to its product's, so the class count is the number of wgrad_ks + wgrad_kernel dispatches.
+    "wgrad": lambda n: ("wgrad_ks_kernel" in n or "wgrad_ks_reduce_kernel" in n or "ge2e::wgrad_kernel" in n or "ge2e12wgrad_kernel" in n),
     "wgrad_reduce": lambda n: "wgrad_ks_reduce_kernel" in n,
     "ffn": lambda n: "ffn_chain_kernel" in n,
     "attn_fwd": lambda n: "attn_fwd_kernel" in n,
@@ -68,7 +71,8 @@ def main():
         for r in rows:
             if pred(r[0]):
                 tot += (r[3] + r[5]) * r[1]
-                n += r[1]
+                if not (name == "wgrad" and "wgrad_ks_reduce_kernel" in r[0]):     # a reduce pass belongs to its product's launch
+                    n += r[1]
         if n:
             classes[name] = round(tot / n)
     json.dump(classes, open(out + "_pmc_traffic.json", "w"), indent=1)
