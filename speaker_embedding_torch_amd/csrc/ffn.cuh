@@ -23,6 +23,19 @@
 //     is then already in this lane's registers and a row's LayerNorm statistics are a lane-quartet reduction;
 //   * LDS images are lane-linear per DMA instruction; XOR swizzles go on the SOURCE address and on the fragment reads, chosen
 //     so that every ds_read_b128 of the permuted rows is bank-conflict free.
+//
+// BWD = true (round 3) is the same machine run backwards through the block, one launch for what were three (norm2 backward, the dF
+// GEMM, the dH1 GEMM):
+//     dP = LayerNorm2'(dH; h2)      dM = drop2'(dP)      dF = (dM . W2) o relu'/drop1' (the forward's mask bits)      dH1 = dP + dF . W1
+//   * pass prologue: the wave's 32 rows of dH and h2 arrive in the operand-fragment layout (row per lane, 64 of its 256 columns; the
+//     row statistics are lane-quartet reductions as in the forward's LayerNorm); dM leaves as 16-byte pieces (the weight gradient
+//     reads it) and IS the first product's operand; dP never leaves the chip: it is the start value of the dH1 accumulators;
+//   * "W1" is linear2.weight transposed ([F][256]), "W2" is linear1.weight transposed ([256][F]): the stage stream is unchanged;
+//   * hidden epilogue: the fp32 tile is masked by the forward's bits (one byte per lane, row and stage; four stages' bytes arrive as
+//     ONE 4-byte-per-lane LDS-DMA per row tile into a wave-private ring -- an ordinary load inside the stage loop would make the
+//     compiler drain the weight ring in front of its use), packed, stored once (dF, for the weight gradient) and fed to product 2;
+//   * pass epilogue: store dH1.
+// The LayerNorm's dgamma / dbeta (column sums over ALL rows) are left to ln_colsum_kernel on the weight-gradient stream.
 #pragma once
 #include "gemm_kl.cuh"
 
@@ -42,6 +55,10 @@ struct FfnArgs {
     Drop drop1, drop2;             // dropout after ReLU (counter row * F + col), dropout2 (counter row * 256 + col)
     int drow_mul;                  // dropout counter row = row * drow_mul (0 = 1)
     int M;
+    // BWD only.  A / lda: dH (the block output's gradient); Y: h2 (the saved LayerNorm output); rstd: read; dM: [M, 256], drop2' of
+    // norm2's input gradient dP (dP itself never leaves the chip); W1 = linear2.weight^T, W2 = linear1.weight^T; Fo = dF; Mb is READ;
+    // C = dH1; drop1.scale masks dF, drop2 masks dM.
+    const void* Y; void* dM;
 };
 
 // Mask-bit layout of a row (128 bytes): the chained kernel's lane (i, g) produces, stage after stage (32 units each), the bits of
@@ -71,15 +88,18 @@ template <int N> __device__ __forceinline__ void ffn_lds_wait(u32x4& f) { asm vo
 
 template <int WV> constexpr int ffn_nstg() { return WV == 8 ? 4 : 2; }
 template <int WV> constexpr size_t ffn_smem() { return (size_t)ffn_nstg<WV>() * FFN_SLOT + (FFN_F + 3 * 256) * 4; }
+// BWD: the same table area (gamma, beta, 1 / gamma in place of b2, gamma, beta) + the mask-word ring: [wave][slot 0 / 1][row tile][64 lanes]
+template <int WV> constexpr size_t ffn_bwd_smem() { return ffn_smem<WV>() + (size_t)WV * 2 * 2 * 256; }
 
 // grid = persistent blocks of 512 threads, one per CU at most, sized so that every block runs the same number of passes
 // ABL (development only, tools/ffn_bench.hip): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no barrier, 16 no hidden epilogue
 // STAGGER: waves 4-7 lag by one product (see the stage loop).  Measured at 153,600 rows: train (dropout hashes + hidden store in the
 // hidden epilogue) 310 -> 279 us with it, eval (a light epilogue) 215 -> 243 us: the launcher staggers train mode only.
-template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F, int WV = 8>
+template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F, int WV = 8, bool BWD = false>
 __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(const FfnArgs p, const int npass) {
     static_assert(sizeof(T) == 2, "16-bit storage modes (bf16_t / f16_t)");
     static_assert(WV == 8 || WV == 4, "waves per block");
+    static_assert(!BWD || STORE_F, "the backward chain stores dF");
     constexpr int NCH = FFN_F / 32;              // stages per pass
     constexpr int NSTG = ffn_nstg<WV>(), D = NSTG - 1;
     constexpr int NDMA = 32 / WV;                // DMA instructions per wave and stage
@@ -88,7 +108,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Ring = smem;                                      // [NSTG][32 KB]: W1 slice | W2 slice
     float* const B1s = (float*)(smem + NSTG * FFN_SLOT);                   // [1024]
-    float* const Ls = B1s + FFN_F;                                         // b2, gamma, beta [3][256]
+    float* const Ls = B1s + FFN_F;                                         // b2, gamma, beta [3][256]   (BWD: gamma, beta, 1 / gamma)
+    [[maybe_unused]] unsigned char* const Mr = (unsigned char*)(Ls + 3 * 256);   // BWD: mask words, this wave's part at + wave * 1024
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,8 +119,12 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
     const int my = b < npass ? (npass - b + G - 1) / G : 0;
     if (my == 0) return;
 
+    if constexpr (BWD) {
+        if (tid < 256) { const float gq = p.gamma[tid]; Ls[tid] = gq; Ls[256 + tid] = p.beta[tid]; Ls[512 + tid] = gq != 0.0f ? 1.0f / gq : 0.0f; }
+    } else {
     for (int q = tid; q < FFN_F; q += 64 * WV) B1s[q] = p.b1[q];
     if (tid < 256) { Ls[tid] = p.b2[tid]; Ls[256 + tid] = p.gamma[tid]; Ls[512 + tid] = p.beta[tid]; }
+    }
     __syncthreads();                              // no DMA in flight yet: an ordinary barrier
 
     const unsigned char* const W1g = (const unsigned char*)p.W1;
@@ -197,6 +222,20 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         asm volatile("" : "+v"(a2[0]), "+v"(a2[1]));
     };
 
+    // BWD: the forward's mask bits of stage group q (stages 4q .. 4q + 3) for this wave's two row tiles: lane (i, g) fetches the word
+    // of row (rt, i), units 128 q + 32 (c & 3) + 8 g .. + 7 in byte c & 3 (ffn_mask_byte), by one 4-byte-per-lane LDS-DMA per row tile
+    // into slot q & 1 of the wave's own ring (read back at lane * 4: no barrier, the wave's counted waits cover it)
+    [[maybe_unused]] auto issue_mask = [&](int q, int m0w) {
+        if constexpr (BWD) {
+            int ln = lane; asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                int gr = m0w + 16 * rt + (ln & 15); gr = gr < last_row ? gr : last_row;
+                glds4(p.Mb + (size_t)gr * (FFN_F / 8) + 16 * q + 4 * (ln >> 4), Mr + wave * 1024 + (q & 1) * 512 + rt * 256);
+            }
+        }
+    };
+
 #pragma unroll 1
     for (int ps = 0; ps < my; ++ps) {
         const int m0 = (b + ps * G) * (32 * WV) + 32 * wave;
@@ -208,6 +247,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         lane_ids(pi, pg);
         // ---- this wave's 32 rows of h1 as operand fragments: af[rt][kg] = h1[row][32 kg + 8g .. + 7]
         u32x4 af[2][8];
+        f32x4 oacc[2][16];                           // (BWD: starts as dP, the residual path of dH1 = dP + dF . W1; else 0)
+        if constexpr (!BWD) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt) {
             int gr = m0 + 16 * rt + pi; gr = gr < last_row ? gr : last_row;
@@ -215,6 +256,78 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
             asm volatile("" : "+v"(arow));
 #pragma unroll
             for (int kg = 0; kg < 8; ++kg) af[rt][kg] = *(const u32x4*)(arow + kg * 64);
+        }
+        } else {
+            // ---- norm2 backward of the wave's 32 rows, in the fragment layout (lane (i, g): row i, columns 32 kg + 8 g .. + 7):
+            //   xh = (y - beta) / gamma, gy = dy gamma, dP = rstd (gy - mean(gy) - xh mean(gy xh)), dM = drop2'(dP) = product 1's operand
+            issue_mask(0, m0);                       // the mask words of stages 0-3 (complete behind the wait below)
+            unsigned tb = (unsigned)(NSTG * FFN_SLOT + FFN_F * 4) + (unsigned)(32 * pg);         // &Ls[8 g], opaque
+            asm volatile("" : "+v"(tb));
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const int row = m0 + 16 * rt + pi;
+                const int gr = row < last_row ? row : last_row;
+                const unsigned char* drow = Ag + (size_t)gr * p.lda * 2 + pg * 16;
+                const unsigned char* yrow = (const unsigned char*)p.Y + (size_t)gr * 512 + pg * 16;
+                asm volatile("" : "+v"(drow), "+v"(yrow));
+                u32x4 dyf[8], yf[8];
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) { dyf[kg] = *(const u32x4*)(drow + kg * 64); yf[kg] = *(const u32x4*)(yrow + kg * 64); }
+                const float rs = p.rstd[gr];
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    const T* const dv = (const T*)&dyf[kg];
+                    const T* const yv = (const T*)&yf[kg];
+                    asm volatile("" : "+v"(tb));        // (every group re-reads its table entries: hoisted, the 3 x 64 table values per lane spill)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x4 ga = *(const f32x4*)(smem + tb + (32 * kg + 4 * hh) * 4), be = *(const f32x4*)(smem + tb + 1024 + (32 * kg + 4 * hh) * 4);
+                        const f32x4 ig = *(const f32x4*)(smem + tb + 2048 + (32 * kg + 4 * hh) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gy = to_f32(dv[4 * hh + r]) * ga[r], xh = (to_f32(yv[4 * hh + r]) - be[r]) * ig[r];
+                            s1 += gy; s2 += gy * xh;
+                        }
+                    }
+                }
+                s1 = cross4_sum(s1) * (1.0f / 256.0f);
+                s2 = cross4_sum(s2) * (1.0f / 256.0f);
+                // the second sweep widens the PACKED values again (kept as 128 fp32 values between the sweeps they spill)
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) asm volatile("" : "+v"(dyf[kg]), "+v"(yf[kg]));
+                unsigned char* mrow = (unsigned char*)p.dM + ((size_t)row * 256 + 8 * pg) * 2;
+                asm volatile("" : "+v"(mrow));
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    const T* const dv = (const T*)&dyf[kg];
+                    const T* const yv = (const T*)&yf[kg];
+                    asm volatile("" : "+v"(tb));
+                    f32x4 dx[2];
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f32x4 ga = *(const f32x4*)(smem + tb + (32 * kg + 4 * hh) * 4), be = *(const f32x4*)(smem + tb + 1024 + (32 * kg + 4 * hh) * 4);
+                        const f32x4 ig = *(const f32x4*)(smem + tb + 2048 + (32 * kg + 4 * hh) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float gy = to_f32(dv[4 * hh + r]) * ga[r], xh = (to_f32(yv[4 * hh + r]) - be[r]) * ig[r];
+                            dx[hh][r] = rs * (gy - s1 - xh * s2);
+                        }
+                        // dP stays on chip: it is the start value of the dH1 accumulators (column 32 kg + 8 g + 4 hh + r of row (rt, i) is
+                        // oacc[rt][2 kg + hh][r], the map of the operand fragments), unrounded
+                        oacc[rt][2 * kg + hh] = dx[hh];
+                    }
+                    // dM = drop2'(dP): masked in fp32, rounded once -- the bits the separate norm2-backward kernel stores
+                    if (p.drop2.thr != 0) {
+#pragma unroll
+                        for (int hh = 0; hh < 2; ++hh)
+                            drop_apply4(p.drop2, (uint32_t)row * drm * 256u + (uint32_t)(32 * kg + 8 * pg + 4 * hh), dx[hh]);
+                    }
+                    const u32x4 pk = pack_acc<T>(dx[0], dx[1]);
+                    if (row < p.M) __builtin_nontemporal_store(pk, (u32x4*)(mrow + 64 * kg));      // the weight gradient dW2 = dM^T f reads it
+                    af[rt][kg] = pk;
+                }
+            }
         }
         // retire these ordinary loads HERE (and with them everything older): the stage loop then contains no load the compiler
         // has to wait for, so its own waits stay out of it, and the counted wait below may assume the steady state from stage 0
@@ -227,11 +340,12 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         __builtin_amdgcn_s_barrier();             // every wave's pieces of the next D stages have landed
         __builtin_amdgcn_sched_barrier(0);
 
-        f32x4 oacc[2][16];
+        if constexpr (!BWD) {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) oacc[rt][nt] = f32x4{0, 0, 0, 0};
+        }
         uint32_t macc[2] = {0u, 0u};                   // train: mask bytes of four stages (see ffn_mask_byte)
 
         // The fragment reads run one group (2 fragments = 4 MFMAs) ahead of the matrix pipe: wA / wB alternate, and every
@@ -274,9 +388,24 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
             lane_ids(i, g);
             unsigned bb = (unsigned)(NSTG * FFN_SLOT) + (unsigned)(c * 128 + 32 * g);      // &B1s[32 c + 8 g], opaque: constants stay in the offset field
             asm volatile("" : "+v"(bb));
+            [[maybe_unused]] unsigned mb = 0;
+            if constexpr (BWD) {                       // this lane's mask words of the stage group: Mr + wave KB + slot + lane * 4 (+ 256 for row tile 1)
+                int ln = lane; asm volatile("" : "+v"(ln));
+                mb = (unsigned)(NSTG * FFN_SLOT + (FFN_F + 3 * 256) * 4) + (unsigned)(wave * 1024 + ((c >> 2) & 1) * 512) + (unsigned)ln * 4u;
+                asm volatile("" : "+v"(mb));
+            }
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
                 const int row = m0 + 16 * rt + i;
+                if constexpr (BWD) {
+                    // dF = (dM . W2) o mask: bit j of this stage's byte <-> hidden unit 32 c + 8 g + j "kept and positive" in the forward
+                    const uint32_t by = *(const uint32_t*)(smem + mb + rt * 256) >> (8 * (c & 3));
+                    if constexpr ((ABL & 16) == 0)
+#pragma unroll
+                    for (int ht = 0; ht < 2; ++ht)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[rt][ht][r] = ((by >> (4 * ht + r)) & 1u) ? h[rt][ht][r] * p.drop1.scale : 0.0f;
+                } else {
 #pragma unroll
                 for (int ht = 0; ht < 2; ++ht) {
                     const int col = c * 32 + 8 * g + 4 * ht;
@@ -286,6 +415,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                     else (void)relu_drop_apply4(Drop{0u, 0u, 1.0f}, 0u, h[rt][ht]);      // the eval kernel: no dropout (the launcher checks)
                     }
                 }
+                }
                 hp[rt] = pack_acc<T>(h[rt][0], h[rt][1]);      // 8 consecutive hidden units 32c + 8g .. + 7 of row (rt, i)
                 if constexpr (STORE_F) {
                     if (row < p.M) {       // 32-bit offset in 16-byte units (rows x F x 2 B stays below 2^36 B for every shape the library accepts)
@@ -293,6 +423,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                         asm volatile("" : "+v"(fo));
                         __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + (size_t)fo * 16));
                     }
+                }
+                if constexpr (STORE_F && !BWD) {
                     // "stored value != 0" of the 8 packed 16-bit values (they are +0 or positive): a packed min against 1 leaves
                     // bit 0 / bit 16 of word k for units 2k / 2k + 1 (building the bits from the compares costs twice the VALU)
                     uint32_t tb = 0;
@@ -369,6 +501,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 u32x4 hp[2];
                 if (c > 0) publish_next();             // stage 0 was published by the pass-start barrier
                 else { issue(); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (BWD) { if ((c & 3) == 0 && c + 4 < NCH) issue_mask((c >> 2) + 1, m0); }
                 stage_bases(c & 1, a1, a2);            // NCH is even: stage c of every pass sits in slot c & 1
                 ffn_static_for<0, FRD>(rd);
 #pragma unroll
@@ -399,6 +532,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 unsigned n1[4], n2[2];
                 prod1(h, a1, a2);
                 publish_next();
+                if constexpr (BWD) { if ((c & 3) == 0 && c + 4 < NCH) issue_mask((c >> 2) + 1, m0); }
                 hidden_epilogue(h, hp, c);
                 c_slot = c_slot + 1 == NSTG ? 0 : c_slot + 1;
                 stage_bases(c_slot, n1, n2);
@@ -413,6 +547,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
             {   // stage 0: no product 2 is pending yet
                 f32x4 h[2][2];
                 publish_next();
+                if constexpr (BWD) issue_mask(1, m0);
                 prod1(h, a1, a2);
                 hidden_epilogue(h, hp, 0);
                 pa2[0] = a2[0]; pa2[1] = a2[1];
@@ -424,6 +559,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 f32x4 h[2][2];
                 prod2(hp, pa2, a1);                // product 2 of stage c - 1, then the first W1 fragments of stage c
                 publish_next();
+                if constexpr (BWD) { if ((c & 3) == 0 && c + 4 < NCH) issue_mask((c >> 2) + 1, m0); }
                 prod1(h, a1, a2);
                 hidden_epilogue(h, hp, c);
                 pa2[0] = a2[0]; pa2[1] = a2[1];
@@ -447,6 +583,19 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
         lane_ids(ei, eg);
         unsigned lb = (unsigned)(NSTG * FFN_SLOT + FFN_F * 4) + (unsigned)(32 * eg);         // &Ls[8 g]
         asm volatile("" : "+v"(lb));
+        if constexpr (BWD) {
+            // ---- dH1 = dP + dF . W1 (dP was the accumulators' start value)
+#pragma unroll
+            for (int rt = 0; rt < ((ABL & 64) ? 0 : 2); ++rt) {
+                const int i = ei, g = eg;
+                const int row = m0 + 16 * rt + i;
+                unsigned char* crow = (unsigned char*)Cg + ((size_t)row * p.ldc + 8 * g) * 2;
+                asm volatile("" : "+v"(crow));
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg)
+                    if (row < p.M) __builtin_nontemporal_store(pack_acc<T>(oacc[rt][2 * kg], oacc[rt][2 * kg + 1]), (u32x4*)(crow + 64 * kg));
+            }
+        } else {
 #pragma unroll
         for (int rt = 0; rt < ((ABL & 64) ? 0 : 2); ++rt) {
             const int i = ei, g = eg;                  // (shadow the kernel-scope lane ids)
@@ -498,6 +647,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                 }
                 if (row < p.M) __builtin_nontemporal_store(pack_acc<T>(o2[0], o2[1]), (u32x4*)(crow + 64 * kg));
             }
+        }
         }
     }
     if constexpr (ABL & 64) { if (p.M < 0) { Cg[tid] = from_f32<T>(oacc_sink); } }

@@ -113,7 +113,13 @@ struct Layout {
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
     size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
-    size_t dHa = 0, dHb = 0, dO = 0;
+    size_t dHb = 0, dO = 0;
+    // dL/d(output of layer l) lives in dHx[(l + 1) % nH] (l = -1: the prenet output).  The weight-gradient stream reads it too (the
+    // norm2 column sums, ln_colsum_kernel), and the layer's last dgrad GEMM writes the NEXT buffer of the rotation: with three buffers a
+    // stack of up to 3 layers never waits for that reader (deeper stacks wait for the reader three layers up).
+    int nH = 1;
+    size_t dHx[3] = {0, 0, 0};
+    size_t dH_of(int l) const { return dHx[(l + 1) % nH]; }
     // Scratch the side stream's weight-gradient kernels read after the main chain has moved on: norm2-backward outputs (dP, dM),
     // norm1-backward outputs (dP2, dM2), dF and dQKV.  Layer l uses set l % nset (dQKV: l % nqkv), so with up to 3 layers the main
     // chain never writes a buffer a weight gradient of the same backward may still be reading -- no main-stream wait (each is a
@@ -175,7 +181,9 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     L.zm = take((size_t)n * d * 4);     L.nrm = take((size_t)n * 4);
     L.emb_keep = take((size_t)n * d * 4); L.d_raw = take((size_t)n * d * 4);
     if (train) {
-        L.dHa = take(R * d * e); L.dHb = take(R * d * e); L.dO = take(R * d * e);
+        L.nH = std::max(1, std::min(c.layers, 3));
+        for (int s = 0; s < L.nH; ++s) L.dHx[s] = take(R * d * e);
+        L.dHb = take(R * d * e); L.dO = take(R * d * e);
         L.nset = c.layers >= 3 ? 2 : 1;              // full-size layers are 0 .. layers - 2 (the last one runs on compact rows)
         L.nqkv = std::min(c.layers, 3);              // dQKV is full-size in every layer
         for (int s = 0; s < L.nset; ++s) {
@@ -411,6 +419,32 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         return 0;
     }
 }
+
+// norm2 backward + dF + dH1 in one launch (ffn_chain_kernel<..., BWD>): same block shapes and grid policy as the forward's train kernel
+template <typename T>
+int launch_ffn_chain_bwd(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
+    if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "ffn chain: 16-bit modes only");
+    else {
+        if (h->num_cus <= 0) {
+            int n = 0;
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, h->device >= 0 ? h->device : 0) != hipSuccess || n <= 0) n = 256;
+            h->num_cus = n;
+        }
+        // the 4-wave shape only (two independent blocks per CU): with dP living in the output accumulators through the prologue the
+        // 8-wave instantiation spills inside its stage loop, and alone the 4-wave shape was the faster one anyway (250 vs 280 us)
+        const int slots = 2 * h->num_cus;
+        const int npass = (a.M + 127) / 128;
+        const int grid = std::min(npass, slots);
+        const double rows = a.M;
+        // algorithmic bytes: dH, h2 in; dM out; mask bits in; dF out; dH1 out; both weight matrices
+        const double abytes = 2.0 * (rows * 256 * 4.0 + rows * FFN_F + 2.0 * 256 * FFN_F) + rows * FFN_F / 8;
+        ProfScope ps(h, st, GE2E_K_FFN, 2.0 * rows * 256 * FFN_F * 2.0, abytes);
+        auto kern = ffn_chain_kernel<T, true, 0, true, 4, true>;
+        GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_bwd_smem<4>(), st, a, npass);
+        return 0;
+    }
+}
+inline bool ffn_chain_bwd_on() { static const bool off = getenv("GE2E_NO_FFN_CHAIN_BWD") != nullptr; return !off; }
 
 // 256 x 256-tile split-K weight gradient (wgrad_ks.cuh) for the wide 16-bit products; everything else (and the rows beyond the
 // last multiple of 32) on the 128 x 128 kernel below.
@@ -857,6 +891,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
     // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
     hipEvent_t g_set1[2] = {nullptr, nullptr}, g_set2[2] = {nullptr, nullptr}, g_dF[2] = {nullptr, nullptr}, g_dQKV[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t g_dH[3] = {nullptr, nullptr, nullptr};    // last weight-gradient-stream reader of dHx[i] (the norm2 column sums)
     {
         TailArgs a{};
         a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
@@ -882,7 +917,28 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         // the last layer runs on compact rows (one per utterance, frame 0) until its attention; see forward_impl
         const bool last = l == c.layers - 1;
         const int Rl = last ? n : R, rmul = last ? t : 1;
-        unsigned char* const b_dH = ws + (last ? L.c_dH : L.dHa);     // dL/d(layer output)
+        unsigned char* const b_dH = ws + (last ? L.c_dH : L.dH_of(l));     // dL/d(layer output)
+        unsigned char* const b_dHin = ws + L.dH_of(l - 1);                // dL/d(layer input): the next buffer of the rotation
+        // norm2 backward + dF + dH1 as ONE launch (ffn.cuh, BWD): full-size layers of the 16-bit modes whose forward left the mask bits
+        auto uses_chain_bwd = [&](int ll) {
+            if constexpr (sizeof(T) != 2) return false;
+            else return ll >= 0 && ll < c.layers - 1 && L.fbits[ll] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && maskbits_on() && ffn_chain_bwd_on();
+        };
+        const bool chain_bwd = uses_chain_bwd(l);
+        // after this layer's last dgrad GEMM: the norm2 column sums of the layer below, on the weight-gradient stream (they read its dL/d(output))
+        bool forked_after_dh = false;
+        auto colsum_below = [&]() -> int {
+            if (!uses_chain_bwd(l - 1)) return 0;
+            sc.fork();                                   // (armed on the dgrad GEMM that wrote b_dHin)
+            forked_after_dh = true;
+            LnBwdArgs a{};
+            a.dy = b_dHin; a.y = ws + L.h2[l - 1]; a.gamma = P[lp(l - 1, L_N2_W)]; a.beta = P[lp(l - 1, L_N2_B)];
+            a.dgamma = G(lp(l - 1, L_N2_W)); a.dbeta = G(lp(l - 1, L_N2_B)); a.R = R;
+            auto kern = ln_colsum_kernel<T>;
+            GE2E_LAUNCH(h, kern, dim3(std::min(512, (R + 31) / 32)), dim3(256), 0, wst, a);
+            g_dH[l % L.nH] = sc.mark();                  // b_dHin = dHx[l % nH]
+            return 0;
+        };
         unsigned char* const b_dHb = ws + (last ? L.c_dHb : L.dHb);
         const int bs = l % L.nset, bq = l % L.nqkv;                   // this layer's buffer sets
         unsigned char* const b_dP = ws + (last ? L.c_dP : L.dP[bs]);
@@ -897,6 +953,19 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         const Drop d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
         const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
         if (!last) sc.wait(g_set1[bs]);                  // (the last layer's compact scratch is written once per backward)
+        unsigned char* gm = d_ff.thr ? b_dM : b_dP;
+        if (chain_bwd) {
+            if constexpr (sizeof(T) == 2) {
+                sc.wait(g_dF[bs]);
+                FfnArgs a{};
+                a.A = b_dH; a.lda = d; a.Y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
+                a.rstd = (float*)(ws + L.rstd2[l]); a.dM = gm;
+                a.W1 = ws + L.w_l2T[l]; a.W2 = ws + L.w_l1T[l]; a.Fo = b_dF; a.ldf = c.ffn; a.Mb = ws + L.fbits[l];
+                a.C = b_dHb; a.ldc = d; a.drop1 = d_fh; a.drop2 = d_ff; a.drow_mul = rmul; a.M = Rl; a.eps = c.ln_eps;
+                sc.arm();
+                CK(launch_ffn_chain_bwd<T>(h, st, a));
+            }
+        } else {
         {   // norm2 backward
             LnBwdArgs a{};
             a.dy = b_dH; a.y = ws + L.h2[l]; a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)];
@@ -906,7 +975,6 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             ProfScope ps(h, st, GE2E_K_LN_BWD, 12.0 * Rl * d, (double)Rl * d * L.esz * (d_ff.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        unsigned char* gm = d_ff.thr ? b_dM : b_dP;
         if (!last) sc.wait(g_dF[bs]);
         {   // dF = (dG W2) masked by ReLU/dropout of the hidden.  (Fusing norm2's backward into this GEMM as it is fused into
             // dO below was measured and lost: its four column-group blocks each redo the LayerNorm prologue, 327 vs 260 us.)
@@ -923,6 +991,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             } else
             CK((gemm128<T, EPI_MASK>(h, st, a)));
         }
+        }
         sc.fork();
         {   // (started right after norm2's backward instead, next to the dF GEMM that streams the same gm and f: no gain, 4.10 vs 4.10 ms)
             WgradArgs a{};
@@ -938,7 +1007,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
             if (!last) g_dF[bs] = sc.mark();
         }
-        {   // dH1 = dPre2 + dF W1
+        if (!chain_bwd) {   // dH1 = dPre2 + dF W1
             GemmArgs a{};
             a.A = b_dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = b_dHb; a.ldc = d;
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
@@ -994,9 +1063,12 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
             g_dQKV[bq] = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
-            g.A = b_dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = ws + L.dHa; g.ldc = d;
+            g.A = b_dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = b_dHin; g.ldc = d;
             g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP2; g.ldr = d;
+            sc.wait(g_dH[l % L.nH]);
+            if (uses_chain_bwd(l - 1)) sc.arm();
             CK((gemm128<T, EPI_ADD>(h, st, g)));
+            CK(colsum_below());
         } else {
             AttnQ0Args a{};   // one query per (utterance, head): dK, dV for every frame, dQ for frame 0
             a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = b_dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
@@ -1021,16 +1093,20 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((gemm128<T, EPI_ADD>(h, st, g0)));
             GemmArgs g{};     // dH(layer input) = dKV Wkv, plus the compact addend on frame-0 rows
             g.A = b_dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
-            g.C = ws + L.dHa; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
+            g.C = b_dHin; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
+            sc.wait(g_dH[l % L.nH]);
+            if (uses_chain_bwd(l - 1)) sc.arm();
             CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
+            CK(colsum_below());
         }
-        if (cb) sc.fork();     // the bucket is final behind the side stream (ge2e_bucket_stream): it now also follows this layer's main-stream kernels
+        if (cb && !forked_after_dh) sc.fork();     // the bucket is final behind the side stream (ge2e_bucket_stream): it now also follows this layer's main-stream kernels
         if (tail_bucket_pending) { bucket(p_fn_w(c), p_proj_b(c)); tail_bucket_pending = false; }
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
     {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place
         GemmArgs a{};
-        a.A = ws + L.xt; a.lda = L.KP; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = ws + L.dHa; a.ldc = d; a.R = ws + L.dHa; a.ldr = d;
+        unsigned char* const dH0 = ws + L.dH_of(-1);
+        a.A = ws + L.xt; a.lda = L.KP; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = dH0; a.ldc = d; a.R = dH0; a.ldr = d;
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
@@ -1039,7 +1115,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         // wait for it, while the side stream's own last job (layer 0's in_proj gradient) ends about when this GEMM does
         // (measured 4.05 vs 4.07 ms per step)
         WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
-        w.Y = ws + L.dHa; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
+        w.Y = dH0; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
         CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));                 // (no split-K scratch here: wpart belongs to the side stream)
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
@@ -1403,7 +1479,8 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
     // backward scratch of FULL-SIZE layer l (name.l): the buffer set that layer uses, see Layout
     else if (train && base == "dP1") { *offset_bytes = L.dP[l % L.nset]; *size_bytes = R * d * e; }  // norm2-backward outputs (set 1)
     else if (train && base == "dM1") { *offset_bytes = L.dM[l % L.nset]; *size_bytes = R * d * e; }
-    else if (train && base == "dHa") { *offset_bytes = L.dHa; *size_bytes = R * d * e; }
+    else if (train && base == "dHa") { *offset_bytes = L.dH_of(l); *size_bytes = R * d * e; }         // dL/d(output of layer l)
+    else if (train && base == "dHin") { *offset_bytes = L.dH_of(l - 1); *size_bytes = R * d * e; }    // dL/d(input of layer l)
     else if (train && base == "dF") { *offset_bytes = L.dF[l % L.nset]; *size_bytes = R * (size_t)h->cfg.ffn * e; }
     else if (train && base == "dHb") { *offset_bytes = L.dHb; *size_bytes = R * d * e; }
     else if (train && base == "dP") { *offset_bytes = L.dP2[l % L.nset]; *size_bytes = R * d * e; }

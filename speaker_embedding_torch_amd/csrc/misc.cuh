@@ -138,6 +138,64 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
     atomicAdd(p.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
 }
 
+// dgamma / dbeta of a LayerNorm alone (the row part of its backward rides in the chained FFN backward kernel, ffn.cuh): column sums over all
+// rows of dy xhat and dy.  Half a wave per row (16 bytes per lane), 4 row pairs in flight per wave, per-lane accumulators for 8 columns;
+// a few hundred blocks, so that the final atomics (every block adds into the same 512 floats) stay a few hundred thousand.  Runs on the
+// weight-gradient stream.
+template <typename T> __device__ __forceinline__ void colsum_load8(const T* p, float* v) {
+    if constexpr (sizeof(T) == 2) {
+        const u32x4 w = *(const u32x4*)p;
+        const T* e = (const T*)&w;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = to_f32(e[q]);
+    } else {
+        const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[q] = a[q]; v[4 + q] = b[q]; }
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256) ln_colsum_kernel(const LnBwdArgs p) {
+    __shared__ float red[2][8][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, c0 = (lane & 31) * 8;
+    float ga[8], be[8], ag[8], ab[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float gq = p.gamma[c0 + q];
+        ga[q] = gq != 0.0f ? 1.0f / gq : 0.0f; be[q] = p.beta[c0 + q]; ag[q] = 0.0f; ab[q] = 0.0f;
+    }
+    constexpr int U = 4;
+    const int slot = (blockIdx.x * 4 + wave) * 2 + half, nslot = gridDim.x * 8;
+    for (int base = slot; base < p.R; base += U * nslot) {
+        float dy[U][8], y[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int row = base + u * nslot;
+            const int rr = row < p.R ? row : base;
+            colsum_load8<T>((const T*)p.dy + (size_t)rr * 256 + c0, dy[u]);
+            colsum_load8<T>((const T*)p.y + (size_t)rr * 256 + c0, y[u]);
+            if (row >= p.R) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dy[u][q] = 0.0f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { ag[q] += dy[u][q] * ((y[u][q] - be[q]) * ga[q]); ab[q] += dy[u][q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { red[0][wave * 2 + half][c0 + q] = ag[q]; red[1][wave * 2 + half][c0 + q] = ab[q]; }
+    __syncthreads();
+    const int c = threadIdx.x;
+    float sg = 0.0f, sb = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) { sg += red[0][w][c]; sb += red[1][w][c]; }
+    atomicAdd(p.dgamma + c, sg);
+    atomicAdd(p.dbeta + c, sb);
+}
+
 // ---------------------------------------------------------------------------------------------
 // tail: z = LN_f(h[n, t=0, :]); z' = mean over `samples`; e = Wq z' + bq; e /= max(|e|, 1e-12)
 // fp32 arithmetic in both modes (0.13 MFLOP/utt).  One block of 256 threads per output embedding.

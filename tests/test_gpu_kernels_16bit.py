@@ -172,7 +172,7 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
             del os.environ["GE2E_DEBUG_BWD_STOP"]
 
     run_backward(1)
-    dy = tap("dHa", (R, d)).clone()                                     # dL/d(h2 of layer 1), written by the last layer's dgrad
+    dy = tap("dHa.1", (R, d)).clone()                                     # dL/d(h2 of layer 1), written by the last layer's dgrad
     run_backward(2)
     l, sv = 1, saved[1]
     pre = f"transformer.layers.{l}."
@@ -188,16 +188,17 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
         assert err < tol, (nm, err)
 
     dx2, dg2, db2 = ln_bwd(dy, sv["h2"], sv["rstd2"], Pf[pre + "norm2.weight"], Pf[pre + "norm2.bias"])
-    dP1, dM1 = tap(f"dP1.{l}", (R, d)), tap(f"dM1.{l}", (R, d))
-    close(dP1, dx2, prec, "norm2 backward (ln_bwd_kernel) dpre")
+    # norm2 backward rides in the prologue of the chained FFN backward: dM (dropout2' of the input gradient dP) is stored for the weight
+    # gradient; dP itself never leaves the chip (it is the start value of the dH1 accumulators, unrounded)
+    dM1 = tap(f"dM1.{l}", (R, d))
     close(dM1, dx2 * keep_rows(O.drop_key(seed, 0, O.site_ff(l)), R, d, p) * scale_d, prec, "norm2 backward dmask")
     wclose(pre + "norm2.weight", dg2); wclose(pre + "norm2.bias", db2)
     dF = tap(f"dF.{l}", (R, ffn))
-    close(dF, (dM1 @ W[pre + "linear2.weight"]) * (sv["f"] > 0).to(F64) * scale_d, prec, "dF = (dG W2) o mask (gemm_ws EPI_MASK)")
+    close(dF, (dM1 @ W[pre + "linear2.weight"]) * (sv["f"] > 0).to(F64) * scale_d, prec, "dF = (dG W2) o mask (chained FFN backward, product 1)")
     wclose(pre + "linear2.weight", dM1.t() @ sv["f"]); wclose(pre + "linear2.bias", dM1.sum(0))
     wclose(pre + "linear1.weight", dF.t() @ sv["h1"]); wclose(pre + "linear1.bias", dF.sum(0))
     dHb = tap("dHb", (R, d))
-    close(dHb, dP1 + dF @ W[pre + "linear1.weight"], prec, "dH1 = dPre2 + dF W1 (gemm_nt EPI_ADD, K = 1024)")
+    close(dHb, dx2 + dF @ W[pre + "linear1.weight"], prec, "dH1 = dPre2 + dF W1 (chained FFN backward, product 2)")
     dx1, dg1, db1 = ln_bwd(dHb, sv["h1"], sv["rstd1"], Pf[pre + "norm1.weight"], Pf[pre + "norm1.bias"])
     dP2, dM2 = tap(f"dP.{l}", (R, d)), tap(f"dM.{l}", (R, d))
     close(dP2, dx1, prec, "norm1 backward in the dO GEMM prologue (gemm_ws_lnbwd) dpre")
@@ -219,6 +220,6 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     dQKV = tap(f"dQKV.{l}", (R, 3 * d))
     close(dQKV, dqkv_ref, prec, "attention backward (attn_bwd_kernel)", l2=0.4, ulps=6.0)
     wclose(pre + "self_attn.in_proj_weight", dQKV.t() @ sv["h_in"]); wclose(pre + "self_attn.in_proj_bias", dQKV.sum(0))
-    dHa = tap("dHa", (R, d))
+    dHa = tap("dHin.1", (R, d))
     close(dHa, dP2 + dQKV @ W[pre + "self_attn.in_proj_weight"], prec, "dH = dPre1 + dQKV Win (gemm_nt EPI_ADD, K = 768)")
     print("\n".join(f"  {a} {c:8.4f} eps  {b}" for a, b, c in OBSERVED[-40:]))
