@@ -576,111 +576,6 @@ __global__ void __launch_bounds__(256) attn_bwd_long_dkv_kernel(const AttnArgs p
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Last layer: only frame t = 0 of the encoder output is consumed (reference Modules.py:54), so its
-// attention needs ONE query per (utterance, head).  fp32 vector math (2*T*64 MACs per head), no MFMA:
-// the kernels are pure K/V streaming.  One block = one utterance, wave h = head h, lane = key (scores)
-// or lane = head dim (outputs).  T <= 64 * KPL.
-// ---------------------------------------------------------------------------------------------
-struct AttnQ0Args {
-    const void* qkv;      // [R, 3D] of T (q valid in rows t = 0 only)
-    void* o0;             // fwd out: [N, D] of T (compact)
-    const void* do0;      // bwd in : [N, D] of T (compact)
-    void* dqkv;           // bwd out: k | v columns of every row written
-    void* dq0;            // bwd out: [N, D] of T (compact) = dL/dq at t = 0
-    int T, H, D;
-    float scale;
-    Drop drop;
-};
-
-namespace attn {
-constexpr int Q0_KPL = 5;     // keys per lane -> T <= 320 (the trained lengths); Q0_KPL_LONG for T <= 1024
-constexpr int Q0_KPL_LONG = 16;
-template <typename T> __device__ __forceinline__ float dot64_row(const T* row, const float* vec) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 64; c += 4) {
-        const f32x4 v = load4(row + c);
-        acc += v[0] * vec[c] + v[1] * vec[c + 1] + v[2] * vec[c + 2] + v[3] * vec[c + 3];
-    }
-    return acc;
-}
-}  // namespace attn
-
-template <typename T, bool BWD, int KPL = attn::Q0_KPL>
-__global__ void __launch_bounds__(256) attn_q0_kernel(const AttnQ0Args p) {
-    __shared__ float qs[4][64], dos[4][64], ps[4][64 * KPL], dss[4][64 * KPL];
-    const int n = blockIdx.x, lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-    if (h >= p.H) return;                                   // heads <= 4 (emb 256 / 64)
-    const size_t ldq = (size_t)3 * p.D;
-    const T* base = (const T*)p.qkv + (size_t)n * p.T * ldq + h * 64;
-    qs[h][lane] = to_f32(base[lane]);                        // q of frame 0
-    if constexpr (BWD) dos[h][lane] = to_f32(((const T*)p.do0)[(size_t)n * p.D + h * 64 + lane]);
-    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): the wave's own LDS writes
-    __builtin_amdgcn_wave_barrier();
-    float s[KPL], dpd[KPL];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int q = 0; q < KPL; ++q) {
-        const int j = lane + 64 * q;
-        s[q] = -INFINITY; dpd[q] = 0.0f;
-        if (j < p.T) {
-            s[q] = attn::dot64_row<T>(base + (size_t)j * ldq + p.D, qs[h]) * p.scale;
-            if constexpr (BWD) dpd[q] = attn::dot64_row<T>(base + (size_t)j * ldq + 2 * p.D, dos[h]);
-        }
-        mx = fmaxf(mx, s[q]);
-    }
-    mx = wave_max(mx);
-    float sum = 0.0f;
-#pragma unroll
-    for (int q = 0; q < KPL; ++q) { s[q] = exp_prec<T>(s[q] - mx); sum += s[q]; }
-    const float inv = 1.0f / wave_sum(sum);
-    const uint32_t ibase = ((uint32_t)(n * p.H + h) * (uint32_t)p.T) * (uint32_t)((p.T + 3) & ~3);   // query 0
-    float delta = 0.0f;
-#pragma unroll
-    for (int q = 0; q < KPL; ++q) {
-        const int j = lane + 64 * q;
-        const float pr = s[q] * inv;
-        const bool keep = p.drop.thr == 0 || drop_keep(ibase + (uint32_t)j, p.drop.key, p.drop.thr);
-        const float pd = keep ? pr * p.drop.scale : 0.0f;
-        if constexpr (BWD) {
-            const float dp = keep ? dpd[q] * p.drop.scale : 0.0f;
-            delta += pr * dp;
-            dpd[q] = dp;
-            s[q] = pr;
-        }
-        if (j < p.T) ps[h][j] = pd;
-    }
-    if constexpr (BWD) {
-        delta = wave_sum(delta);
-#pragma unroll
-        for (int q = 0; q < KPL; ++q) {
-            const int j = lane + 64 * q;
-            if (j < p.T) dss[h][j] = s[q] * (dpd[q] - delta) * p.scale;
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    if constexpr (!BWD) {                                    // o0[d = lane] = sum_j pd_j V[j][lane]
-        float acc = 0.0f;
-        const T* v = base + 2 * p.D + lane;
-#pragma unroll 4
-        for (int j = 0; j < p.T; ++j) acc += ps[h][j] * to_f32(v[(size_t)j * ldq]);
-        ((T*)p.o0)[(size_t)n * p.D + h * 64 + lane] = from_f32<T>(acc);
-    } else {                                                 // dV = pd (x) dO0, dK = dS (x) q0, dQ0 = sum_j dS_j K[j]
-        const float q0 = qs[h][lane], d0 = dos[h][lane];
-        const T* k = base + p.D + lane;
-        T* dk = (T*)p.dqkv + (size_t)n * p.T * ldq + h * 64 + p.D + lane;
-        float acc = 0.0f;
-#pragma unroll 4
-        for (int j = 0; j < p.T; ++j) {
-            const float ds = dss[h][j];
-            acc += ds * to_f32(k[(size_t)j * ldq]);
-            dk[(size_t)j * ldq] = from_f32<T>(ds * q0);
-            dk[(size_t)j * ldq + p.D] = from_f32<T>(ps[h][j] * d0);
-        }
-        ((T*)p.dq0)[(size_t)n * p.D + h * 64 + lane] = from_f32<T>(acc);
-    }
-}
+// (The last layer's single-query attention lives in attn_last.cuh: it needs no K / V projection at all.)
 
 }  // namespace ge2e

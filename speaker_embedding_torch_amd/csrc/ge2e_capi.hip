@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "attention.cuh"
+#include "attn_last.cuh"
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
@@ -111,6 +112,10 @@ struct Layout {
     size_t fbits[MAX_LAYERS];    // [R, ffn / 8] bytes: "stored FFN hidden > 0", one bit per element (train, 16-bit modes, full layers;
                                  // written by the chained FFN kernel, read by the backward's dF GEMM instead of the hidden itself)
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
+    // last layer (attn_last.cuh: one query per utterance, K and V are never materialised): q of frame 0 [n, 256] of T; train mode also keeps
+    // qk = Wk_h^T q0_h [n, 4, 256], the probabilities [n, 4, T], ctx = sum_t pd_t x_t [n, 4, 256], sum_t pd_t [n, 4] (all fp32) and, in
+    // backward, dqk [n, 4, 256]
+    size_t lq0 = 0, lqk = 0, lprob = 0, lctx = 0, lsp = 0, ldqk = 0;
     size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHb = 0, dO = 0;
@@ -157,7 +162,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     if (train) {
         for (int l = 0; l < c.layers; ++l) {
             const size_t Rl = l == last ? (size_t)n : R;
-            L.qkv[l] = take(R * 3 * d * e); L.o[l] = take(Rl * d * e);
+            L.qkv[l] = l == last ? (size_t)-1 : take(R * 3 * d * e); L.o[l] = take(Rl * d * e);
             L.h1[l] = take(Rl * d * e);     L.rstd1[l] = take(Rl * 4);
             L.f[l] = take(Rl * f * e);      L.h2[l] = take(Rl * d * e);
             L.rstd2[l] = take(Rl * 4);
@@ -165,7 +170,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
             L.fbits[l] = (l == last || e != 2 || f % 128 != 0) ? (size_t)-1 : take(R * (f / 8));
         }
     } else {        // eval: layers reuse one set of buffers; h2 overwrites the layer input
-        const size_t qkv = take(R * 3 * d * e);
+        const size_t qkv = c.layers > 1 ? take(R * 3 * d * e) : (size_t)-1;
         size_t o = 0, h1 = 0, ff = 0;
         if (c.layers > 1) { o = take(R * d * e); h1 = take(R * d * e); ff = take(R * f * e); }
         for (int l = 0; l < last; ++l) {
@@ -173,9 +178,14 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
             L.rstd1[l] = L.rstd2[l] = L.lse[l] = L.fbits[l] = (size_t)-1;
         }
         L.lse[last] = L.fbits[last] = (size_t)-1;
-        L.qkv[last] = qkv; L.o[last] = take((size_t)n * d * e); L.h1[last] = take((size_t)n * d * e);
+        L.qkv[last] = (size_t)-1; L.o[last] = take((size_t)n * d * e); L.h1[last] = take((size_t)n * d * e);
         L.f[last] = take((size_t)n * f * e); L.h2[last] = take((size_t)n * d * e);
         L.rstd1[last] = L.rstd2[last] = (size_t)-1;
+    }
+    L.lq0 = take((size_t)n * d * e);
+    if (train) {
+        L.lqk = take((size_t)n * 4 * d * 4); L.lprob = take((size_t)n * 4 * (size_t)t * 4); L.lctx = take((size_t)n * 4 * d * 4);
+        L.lsp = take((size_t)n * 4 * 4); L.ldqk = take((size_t)n * 4 * d * 4);
     }
     L.xhat_f = take((size_t)n * d * 4); L.rstd_f = take((size_t)n * 4);
     L.zm = take((size_t)n * d * 4);     L.nrm = take((size_t)n * 4);
@@ -589,19 +599,15 @@ int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bw
     }
 }
 
-template <typename T>
-int launch_attn_q0(ge2e_handle h, hipStream_t st, const AttnQ0Args& a, int n, bool bwd) {
-    if (a.T > 64 * attn::Q0_KPL_LONG || a.H > 4) return fail(h, GE2E_EUNSUPPORTED, "q0 attention: frames > 1024 or heads > 4");
-    ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 10.0 : 4.0) * a.T * 64.0 * n * a.H,
-                 (double)n * a.T * a.D * sizeof(T) * (bwd ? 4.0 : 2.0));
-    if (a.T <= 64 * attn::Q0_KPL) {
-        if (bwd) { auto kern = attn_q0_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
-        else { auto kern = attn_q0_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
-    } else {        // up to Max_Position 1024: 16 keys per lane
-        if (bwd) { auto kern = attn_q0_kernel<T, true, attn::Q0_KPL_LONG>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
-        else { auto kern = attn_q0_kernel<T, false, attn::Q0_KPL_LONG>; GE2E_LAUNCH(h, kern, dim3(n), dim3(256), 0, st, a); }
-    }
-    return 0;
+// last layer: one query per utterance, no K / V projection (attn_last.cuh)
+inline AttnLastArgs attn_last_args(const ge2e_config& c, const Layout& L, unsigned char* ws, const float* const* P, int l, int t, const void* x,
+                                   bool train, const Drop& drop) {
+    AttnLastArgs a{};
+    const size_t dd = (size_t)c.emb * c.emb * L.esz;
+    a.x = x; a.q0 = ws + L.lq0; a.Wq = ws + L.w_in[l]; a.Wk = ws + L.w_in[l] + dd; a.Wv = ws + L.w_in[l] + 2 * dd; a.bv = P[lp(l, L_IN_B)] + 2 * c.emb;
+    if (train) { a.qk = (float*)(ws + L.lqk); a.prob = (float*)(ws + L.lprob); a.ctx = (float*)(ws + L.lctx); a.sp = (float*)(ws + L.lsp); a.dqk = (float*)(ws + L.ldqk); }
+    a.T = t; a.H = c.heads; a.scale = 1.0f / std::sqrt((float)(c.emb / c.heads)); a.drop = drop;
+    return a;
 }
 
 // A handle's side stream, fence events and CU count belong to ONE device: the one that is current at its first GPU call.
@@ -780,15 +786,16 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.M = R; a.N = 3 * d; a.K = d; a.bias = P[lp(l, L_IN_B)];
             CK((gemm128<T, EPI_BIAS>(h, st, a)));
         } else {
-            GemmArgs a{};   // k | v of every frame
-            a.A = hin; a.lda = d; a.W = ws + L.w_in[l] + (size_t)d * d * esz; a.ldw = d;
-            a.C = ws + L.qkv[l] + (size_t)d * esz; a.ldc = 3 * d;
-            a.M = R; a.N = 2 * d; a.K = d; a.bias = P[lp(l, L_IN_B)] + d;
-            CK((gemm128<T, EPI_BIAS>(h, st, a)));
-            GemmArgs q{};   // q of frame 0: rows n*T of hin -> rows n*T of qkv
-            q.A = hin; q.lda = d * t; q.W = ws + L.w_in[l]; q.ldw = d; q.C = ws + L.qkv[l]; q.ldc = 3 * d * t;
+            GemmArgs q{};   // q of frame 0: rows n * T of hin -> compact rows
+            q.A = hin; q.lda = d * t; q.W = ws + L.w_in[l]; q.ldw = d; q.C = ws + L.lq0; q.ldc = d;
             q.M = n; q.N = d; q.K = d; q.bias = P[lp(l, L_IN_B)];
             CK((gemm128<T, EPI_BIAS>(h, st, q)));
+            // one query per (utterance, head): scores and context straight from the layer input, K and V never exist (attn_last.cuh)
+            AttnLastArgs a = attn_last_args(c, L, ws, P, l, t, hin, train, make_drop(train, c.tf_dropout, seed, step, site_attn(l)));
+            a.o0 = ws + L.o[l];
+            ProfScope ps(h, st, GE2E_K_ATTN_FWD, 4.0 * t * 256.0 * 4.0 * n, (double)n * t * d * sizeof(T));
+            auto kern = attn_last_fwd_kernel<T>;
+            GE2E_LAUNCH(h, kern, dim3(n), dim3(256), attn_last_fwd_smem(t), st, a);
         }
         if (!last) {   // softmax(q k^T / 8) v per (utterance, head)
             AttnArgs a{};
@@ -797,12 +804,6 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
             CK(launch_attn<T>(h, st, a, n, false));
-        } else {
-            AttnQ0Args a{};
-            a.qkv = ws + L.qkv[l]; a.o0 = ws + L.o[l]; a.T = t; a.H = c.heads; a.D = d;
-            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
-            a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
-            CK(launch_attn_q0<T>(h, st, a, n, false));
         }
         {   // out_proj + dropout1 + residual + norm1
             GemmArgs a{};
@@ -927,9 +928,9 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         const bool chain_bwd = uses_chain_bwd(l);
         // after this layer's last dgrad GEMM: the norm2 column sums of the layer below, on the weight-gradient stream (they read its dL/d(output))
         bool forked_after_dh = false;
-        auto colsum_below = [&]() -> int {
+        auto colsum_below = [&](bool already_forked = false) -> int {
             if (!uses_chain_bwd(l - 1)) return 0;
-            sc.fork();                                   // (armed on the dgrad GEMM that wrote b_dHin)
+            if (!already_forked) sc.fork();              // (armed on the dgrad GEMM that wrote b_dHin)
             forked_after_dh = true;
             LnBwdArgs a{};
             a.dy = b_dHin; a.y = ws + L.h2[l - 1]; a.gamma = P[lp(l - 1, L_N2_W)]; a.beta = P[lp(l - 1, L_N2_B)];
@@ -1070,34 +1071,31 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((gemm128<T, EPI_ADD>(h, st, g)));
             CK(colsum_below());
         } else {
-            AttnQ0Args a{};   // one query per (utterance, head): dK, dV for every frame, dQ for frame 0
-            a.qkv = ws + L.qkv[l]; a.do0 = b_dO; a.dqkv = b_dQKV; a.dq0 = ws + L.c_dQ0; a.T = t; a.H = c.heads; a.D = d;
-            a.scale = 1.0f / std::sqrt((float)(d / c.heads));
-            a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
+            // one query per (utterance, head), K / V never materialised (attn_last.cuh): dL/d(layer input) of every frame -- the K / V
+            // path, plus the residual path and the query on the frame-0 rows -- in ONE launch; dq0 and dqk for the weight gradients
+            AttnLastArgs a = attn_last_args(c, L, ws, P, l, t, hin, true, make_drop(true, c.tf_dropout, seed, step, site_attn(l)));
+            a.do0 = b_dO; a.dpre = b_dP2; a.dX = b_dHin; a.dq0 = ws + L.c_dQ0;
+            sc.wait(g_dH[l % L.nH]);
             sc.arm();
-            CK(launch_attn_q0<T>(h, st, a, n, true));
+            {
+                ProfScope ps(h, st, GE2E_K_ATTN_BWD, 10.0 * t * 256.0 * 4.0 * n, (double)n * t * d * sizeof(T) * 2.0);
+                auto kern = attn_last_bwd_kernel<T>;
+                GE2E_LAUNCH(h, kern, dim3(n), dim3(256), attn_last_bwd_smem(t), st, a);
+            }
             sc.fork();
-            WgradArgs wkv{};  // k | v rows of in_proj_weight from every frame
-            wkv.Y = b_dQKV + (size_t)d * esz; wkv.ldy = 3 * d; wkv.X = hin; wkv.ldx = d;
-            wkv.dW = G(lp(l, L_IN_W)) + (size_t)d * d; wkv.ldw = d; wkv.db = G(lp(l, L_IN_B)) + d;
-            wkv.R = R; wkv.N = 2 * d; wkv.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wkv, wpart)));
+            forked_after_dh = true;
+            {   // k | v rows of in_proj_weight (and the v bias; the k bias has no gradient: its score term is constant over the frames)
+                auto kern = attn_last_wgrad_kernel<T>;
+                const int chunks = std::max(1, std::min(8, n / 64)), per = (n + chunks - 1) / chunks;
+                float* const dW = G(lp(l, L_IN_W));
+                GE2E_LAUNCH(h, kern, dim3(512, chunks), dim3(256), 0, wst, (const void*)(ws + L.lq0), (const float*)(ws + L.ldqk), (const void*)b_dO,
+                            (const float*)(ws + L.lctx), (const float*)(ws + L.lsp), dW + (size_t)d * d, dW + (size_t)2 * d * d, G(lp(l, L_IN_B)) + 2 * d, n, per);
+            }
             WgradArgs wq{};   // q rows from frame 0 of every utterance
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wq)));
-            g_dQKV[bq] = sc.mark();
-            GemmArgs g0{};    // frame-0 addend: dPre1 + dQ0 Wq   (compact)
-            g0.A = ws + L.c_dQ0; g0.lda = d; g0.W = ws + L.w_inT[l]; g0.ldw = 3 * d; g0.C = ws + L.c_tmp; g0.ldc = d;
-            g0.M = n; g0.N = d; g0.K = d; g0.R = b_dP2; g0.ldr = d;
-            CK((gemm128<T, EPI_ADD>(h, st, g0)));
-            GemmArgs g{};     // dH(layer input) = dKV Wkv, plus the compact addend on frame-0 rows
-            g.A = b_dQKV + (size_t)d * esz; g.lda = 3 * d; g.W = ws + L.w_inT[l] + (size_t)d * esz; g.ldw = 3 * d;
-            g.C = b_dHin; g.ldc = d; g.M = R; g.N = d; g.K = 2 * d; g.R = ws + L.c_tmp; g.ldr = d; g.T = t;
-            sc.wait(g_dH[l % L.nH]);
-            if (uses_chain_bwd(l - 1)) sc.arm();
-            CK((gemm128<T, EPI_ADD_ROW0>(h, st, g)));
-            CK(colsum_below());
+            CK(colsum_below(true));
         }
         if (cb && !forked_after_dh) sc.fork();     // the bucket is final behind the side stream (ge2e_bucket_stream): it now also follows this layer's main-stream kernels
         if (tail_bucket_pending) { bucket(p_fn_w(c), p_proj_b(c)); tail_bucket_pending = false; }
@@ -1467,7 +1465,8 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
     const bool lastl = l == h->cfg.layers - 1;
     const size_t Rl = lastl ? (size_t)n_utts : R;     // the last layer keeps compact rows (frame 0 only)
     if (base == "h0") { *offset_bytes = L.h0; *size_bytes = R * d * e; }
-    else if (base == "qkv") { *offset_bytes = L.qkv[l]; *size_bytes = R * 3 * d * e; }
+    else if (base == "qkv" && !lastl) { *offset_bytes = L.qkv[l]; *size_bytes = R * 3 * d * e; }
+    else if (base == "q0") { *offset_bytes = L.lq0; *size_bytes = (size_t)n_utts * d * e; }               // the last layer's query, frame 0 (compact)
     else if (base == "o") { *offset_bytes = L.o[l]; *size_bytes = Rl * d * e; }
     else if (base == "h1") { *offset_bytes = L.h1[l]; *size_bytes = Rl * d * e; }
     else if (base == "f") { *offset_bytes = L.f[l]; *size_bytes = Rl * (size_t)h->cfg.ffn * e; }

@@ -104,12 +104,14 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
         Rl, rmul = (n, t) if last else (R, 1)
         rows0 = torch.arange(n) * t                                   # frame-0 rows
         hin_c = h_in[rows0] if last else h_in                         # rows the layer's compact part works on
-        qkv = tap(f"qkv.{l}", (R, 3 * d))
         qkv_ref = h_in @ W[pre + "self_attn.in_proj_weight"].t() + Pf[pre + "self_attn.in_proj_bias"]
-        if last:     # K | V of every frame, Q of frame 0 only
-            close(qkv[:, d:], qkv_ref[:, d:], prec, f"in_proj k|v layer {l} (gemm_ws EPI_BIAS)")
-            close(qkv[rows0, :d], qkv_ref[rows0, :d], prec, f"in_proj q0 layer {l}")
+        if last:     # Q of frame 0 only; K and V are never materialised (attn_last.cuh works on the layer input): fp64 K | V here
+            q0 = tap("q0", (n, d))
+            close(q0, qkv_ref[rows0, :d], prec, f"in_proj q0 layer {l}")
+            qkv = qkv_ref.clone()
+            qkv[rows0, :d] = q0
         else:
+            qkv = tap(f"qkv.{l}", (R, 3 * d))
             close(qkv, qkv_ref, prec, f"in_proj layer {l} (gemm_ws EPI_BIAS)")
         # attention on the tapped q, k, v
         q, k, v = [qkv[:, i * d:(i + 1) * d].reshape(n, t, heads, 64).permute(0, 2, 1, 3) for i in range(3)]
