@@ -42,7 +42,10 @@ def close(got, ref, prec, what, l2=0.05, ulps=3.0):
     """`got` (device output, already in the storage type) vs `ref` (fp64, NOT yet rounded)."""
     got, want = got.to(F64), rt(ref, prec)
     err = (got - want).norm().item() / max(want.norm().item(), 1e-30)
-    bound = l2 * EPS[prec]
+    # device value and expectation are both ROUNDED values: they differ where the fp32-vs-fp64 sums fall on the two sides of a rounding
+    # boundary, one unit in the last place at a time.  On the last layer's compact tensors (one row per utterance: ~1,500 elements) a
+    # single such flip is already ~0.05 roundoffs of relative L2, so the bound allows three flips of the largest elements on top
+    bound = EPS[prec] * (l2 ** 2 + 3.0 * 4.0 * (want.abs().max().item() / max(want.norm().item(), 1e-30)) ** 2) ** 0.5
     OBSERVED.append((prec, what, round(err / EPS[prec], 4)))
     assert torch.isfinite(got).all(), what
     assert err < bound, (what, err, bound)
