@@ -44,57 +44,85 @@ struct AttnLastArgs {
     int T, H;
     float scale;          // 1 / sqrt(64)
     Drop drop;
+    int abl;              // development only (tools/attn_last_bench.hip): bit k skips phase k of the kernel; 0 in the library
 };
 
 namespace attn_last {
 constexpr int D = 256;
-__device__ __forceinline__ float dot4(const f32x4 a, const f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
-
-// out[h][t] = (vec_h . x_t) * mul + add[h]  for the block's utterance: wave w takes rows t = w (mod 4), four rows in flight
+// Cross-lane reductions are what a vector formulation of these products costs (a wave_sum is six LDS-crossbar permutes: 160 of them
+// per wave and sweep made the score sweep 52 of the forward's 95 us), so the two product shapes that would need them run on the
+// matrix pipe instead, with 12 of the 16 operand rows / columns left zero -- the FLOPs are negligible either way:
+//   sweep_mfma : out[h][t] = vec_h . x_t          (4 x 256 by 256 x T: the four heads are rows 0-3 of the "weight" operand)
+//   rows_mfma  : out[r]    = W[r] . vec  (64 rows) (the vector is row 0 of the "activation" operand)
+// Operand fragments are the library's usual ones (common.cuh: 16 bytes per lane, lane (i, g) = row i, k-slots of g), so x rows and
+// W rows are plain 16-byte global loads.  fp32 mode uses the exact fp32 MFMA.
+template <typename T> __device__ __forceinline__ u32x4 frag_from_f32(const float* v) {      // v: this lane's FRAG consecutive k values
+    if constexpr (sizeof(T) == 4) return pack_acc<T>(*(const f32x4*)v, f32x4{0, 0, 0, 0});
+    else return pack_acc<T>(*(const f32x4*)v, *(const f32x4*)(v + 4));
+}
+// out[h][t] = (vec_h . x_t) * mul + add[h], h = 0..3, for the rows of the block's utterance; wave w takes the 16-row tiles w, w + 4, ...
 template <typename T>
-__device__ __forceinline__ void sweep_dot(const T* xb, int Tn, const float* vec /* [4][256] LDS */, float* out /* [4][Tn] LDS */,
-                                          float mul, const float* add, int w, int lane) {
-    f32x4 v4[4];
+__device__ __forceinline__ void sweep_mfma(const T* xb, int Tn, const float* vec /* [4][256] LDS */, float* out /* [4][Tn] LDS */,
+                                           float mul, const float* add, int w, int lane) {
+    constexpr int KG = Prec<T>::KG, FR = Prec<T>::FRAG, NKG = D / KG;
+    const int i = lane & 15, g = lane >> 4;
+    u32x4 wf[NKG];
 #pragma unroll
-    for (int h = 0; h < 4; ++h) v4[h] = *(const f32x4*)(vec + h * D + 4 * lane);
-    for (int t0 = w; t0 < Tn; t0 += 16) {
-        float s[4][4];
+    for (int kg = 0; kg < NKG; ++kg)
+        wf[kg] = i < 4 ? frag_from_f32<T>(vec + i * D + KG * kg + FR * g) : u32x4{0, 0, 0, 0};
+    for (int j = w; 16 * j < Tn; j += 4) {
+        const int t = 16 * j + i;
+        const unsigned char* xrow = (const unsigned char*)(xb + (size_t)(t < Tn ? t : Tn - 1) * D) + FR * g * sizeof(T);
+        u32x4 xf[NKG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int t = t0 + 4 * u;
-            const f32x4 xv = t < Tn ? load4(xb + (size_t)t * D + 4 * lane) : f32x4{0, 0, 0, 0};
+        for (int kg = 0; kg < NKG; ++kg) xf[kg] = *(const u32x4*)(xrow + kg * KG * sizeof(T));
+        f32x4 acc = f32x4{0, 0, 0, 0};
 #pragma unroll
-            for (int h = 0; h < 4; ++h) s[u][h] = dot4(v4[h], xv);
-        }
+        for (int kg = 0; kg < NKG; ++kg) acc = mma16<T>(wf[kg], xf[kg], acc);       // acc[r] = vec_{4g + r} . x_t
+        if (g == 0 && t < Tn) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) s[u][h] = wave_sum(s[u][h]);
-        if (lane == 0) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + 4 * u;
-                if (t < Tn) {
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) out[h * Tn + t] = s[u][h] * mul + (add ? add[h] : 0.0f);
-                }
-            }
+            for (int r = 0; r < 4; ++r) out[r * Tn + t] = acc[r] * mul + (add ? add[r] : 0.0f);
         }
     }
 }
-// out[64 w + j] = W[64 w + j][:] . vec_w  (j = 0 .. 63) for wave w: lane j ends up holding result j
+// res[64 w + j] = W[64 w + j][:] . vec  (j = 0 .. 63) for wave w; vec: [256] fp32 in LDS, res: LDS
 template <typename T>
-__device__ __forceinline__ float rows_dot(const T* W, const float* vec_w /* [256] LDS */, int w, int lane) {
-    const f32x4 c4 = *(const f32x4*)(vec_w + 4 * lane);
-    float mine = 0.0f;
-    for (int j = 0; j < 64; j += 4) {
-        float d[4];
+__device__ __forceinline__ void rows_mfma(const T* W, const float* vec, float* res, int w, int lane) {
+    constexpr int KG = Prec<T>::KG, FR = Prec<T>::FRAG, NKG = D / KG;
+    const int i = lane & 15, g = lane >> 4;
+    u32x4 vf[NKG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) d[u] = dot4(load4(W + (size_t)(64 * w + j + u) * D + 4 * lane), c4);
+    for (int kg = 0; kg < NKG; ++kg) vf[kg] = i == 0 ? frag_from_f32<T>(vec + KG * kg + FR * g) : u32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { d[u] = wave_sum(d[u]); if (lane == j + u) mine = d[u]; }
+    for (int m = 0; m < 4; ++m) {
+        const unsigned char* wrow = (const unsigned char*)(W + (size_t)(64 * w + 16 * m + i) * D) + FR * g * sizeof(T);
+        u32x4 wf[NKG];
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) wf[kg] = *(const u32x4*)(wrow + kg * KG * sizeof(T));
+        f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) acc = mma16<T>(wf[kg], vf[kg], acc);       // acc[r] = W[64 w + 16 m + 4 g + r] . X[i]; X[0] = vec
+        if (i == 0) *(f32x4*)(res + 64 * w + 16 * m + 4 * g) = acc;
     }
-    return mine;
+}
+// out_w[c] = sum_j vec[64 w + j] W[64 w + j][c] for wave w (= head w): lane = 4 columns, 8 rows in flight (one 8-byte load per lane and row)
+template <typename T>
+__device__ __forceinline__ f32x4 cols_dot(const T* W, const float* vec /* [256] LDS */, int w, int lane) {
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < 64; j += 8) {
+        f32x4 r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = load4(W + (size_t)(64 * w + j + u) * D + 4 * lane);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += vec[64 * w + j + u] * r[u];
+    }
+    return acc;
+}
+// the wave's rows t = w, w + 4, ... of the input tile, 8 at a time: lane = 4 columns; rows past the end are zero
+template <typename T>
+__device__ __forceinline__ void rows8(f32x4* xv, const T* xb, int Tn, int lane, int t0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int t = t0 + 4 * u; xv[u] = t < Tn ? load4(xb + (size_t)t * D + 4 * lane) : f32x4{0, 0, 0, 0}; }
 }
 }  // namespace attn_last
 
@@ -104,7 +132,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p) {
     using namespace attn_last;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* const qs = sm;                      // [256] q0
+    float* const qs = sm;                      // [256] q0, later the output row
     float* const qt = qs + 256;                // [4][256] qk_h, later ctx_h
     float* const sps = qt + 1024;              // [4] sum of the dropped probabilities (+ padding to 256)
     float* const red = sps + 256;              // [4 waves][4 heads][256]
@@ -114,23 +142,15 @@ __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p
     const T* const xb = (const T*)p.x + (size_t)n * Tn * D;
     qs[c] = to_f32(((const T*)p.q0)[(size_t)n * D + c]);
     __syncthreads();
-    {   // qk_h[c] = sum_j q0[64 h + j] Wk[64 h + j][c]
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        const T* wk = (const T*)p.Wk + c;
-#pragma unroll 4
-        for (int j = 0; j < 64; ++j)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) a[h] += qs[64 * h + j] * to_f32(wk[(size_t)(64 * h + j) * D]);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            qt[h * D + c] = a[h];
-            if (p.qk) p.qk[((size_t)n * 4 + h) * D + c] = a[h];
-        }
+    {   // qk_h[c] = sum_j q0[64 h + j] Wk[64 h + j][c]: wave h = head h
+        const f32x4 a = (p.abl & 1) ? f32x4{0, 0, 0, 0} : attn_last::cols_dot<T>((const T*)p.Wk, qs, w, lane);
+        *(f32x4*)(qt + w * D + 4 * lane) = a;
+        if (p.qk) *(f32x4*)(p.qk + ((size_t)n * 4 + w) * D + 4 * lane) = a;
     }
     __syncthreads();
-    sweep_dot<T>(xb, Tn, qt, sc, p.scale, nullptr, w, lane);
+    if (!(p.abl & 2)) sweep_mfma<T>(xb, Tn, qt, sc, p.scale, nullptr, w, lane);
     __syncthreads();
-    if (w < p.H) {   // softmax over the frames of head w, dropout on the probabilities (counter: query 0 of head row n H + w)
+    if (w < p.H && !(p.abl & 4)) {   // softmax over the frames of head w, dropout on the probabilities (counter: query 0 of head row n H + w)
         float* const s = sc + w * Tn;
         float mx = -INFINITY;
         for (int t = lane; t < Tn; t += 64) mx = fmaxf(mx, s[t]);
@@ -160,12 +180,11 @@ __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p
         f32x4 acc[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) acc[h] = f32x4{0, 0, 0, 0};
-        for (int t0 = w; t0 < Tn; t0 += 16) {
-            f32x4 xv[4];
+        for (int t0 = w; t0 < Tn && !(p.abl & 8); t0 += 32) {
+            f32x4 xv[8];
+            rows8<T>(xv, xb, Tn, lane, t0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int t = t0 + 4 * u; xv[u] = t < Tn ? load4(xb + (size_t)t * D + 4 * lane) : f32x4{0, 0, 0, 0}; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int t = t0 + 4 * u;
                 if (t < Tn) {
 #pragma unroll
@@ -184,10 +203,11 @@ __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p
         if (p.ctx) p.ctx[((size_t)n * 4 + h) * D + c] = cx;
     }
     __syncthreads();
-    if (w < p.H) {   // o[64 w + j] = Wv[64 w + j] . ctx_w + bv[64 w + j] sum_t pd_t
-        const float r = attn_last::rows_dot<T>((const T*)p.Wv, qt + w * D, w, lane);
-        ((T*)p.o0)[(size_t)n * D + 64 * w + lane] = from_f32<T>(r + p.bv[64 * w + lane] * sps[w]);
-    } else ((T*)p.o0)[(size_t)n * D + 64 * w + lane] = from_f32<T>(0.0f);
+    // o[64 w + j] = Wv[64 w + j] . ctx_w + bv[64 w + j] sum_t pd_t
+    if (w < p.H && !(p.abl & 16)) attn_last::rows_mfma<T>((const T*)p.Wv, qt + w * D, qs, w, lane);
+    else qs[c] = 0.0f;
+    __syncthreads();
+    ((T*)p.o0)[(size_t)n * D + c] = from_f32<T>(qs[c] + p.bv[c] * sps[w]);
 }
 
 inline size_t attn_last_bwd_smem(int T) { return (size_t)(256 + 1024 + 1024 + 4096 + 256 + 256 + 256 + 8 * T) * 4; }
@@ -210,19 +230,14 @@ __global__ void __launch_bounds__(256) attn_last_bwd_kernel(const AttnLastArgs p
     dos[c] = to_f32(((const T*)p.do0)[(size_t)n * D + c]);
     __syncthreads();
     {
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        const T* wv = (const T*)p.Wv + c;
-#pragma unroll 4
-        for (int j = 0; j < 64; ++j)
+        *(f32x4*)(dct + w * D + 4 * lane) = attn_last::cols_dot<T>((const T*)p.Wv, dos, w, lane);
 #pragma unroll
-            for (int h = 0; h < 4; ++h) a[h] += dos[64 * h + j] * to_f32(wv[(size_t)(64 * h + j) * D]);
-#pragma unroll
-        for (int h = 0; h < 4; ++h) { dct[h * D + c] = a[h]; qks[h * D + c] = p.qk[((size_t)n * 4 + h) * D + c]; }
+        for (int h = 0; h < 4; ++h) qks[h * D + c] = p.qk[((size_t)n * 4 + h) * D + c];
         const float b = wave_sum(dos[c] * p.bv[c]);      // wave w covers columns 64 w .. 64 w + 63 = head w
         if (lane == 0) dob[w] = b;
     }
     __syncthreads();
-    sweep_dot<T>(xb, Tn, dct, dpt, 1.0f, dob, w, lane);
+    sweep_mfma<T>(xb, Tn, dct, dpt, 1.0f, dob, w, lane);
     __syncthreads();
     if (w < p.H) {
         float* const dp = dpt + w * Tn;
@@ -249,12 +264,11 @@ __global__ void __launch_bounds__(256) attn_last_bwd_kernel(const AttnLastArgs p
 #pragma unroll
         for (int h = 0; h < 4; ++h) { acc[h] = f32x4{0, 0, 0, 0}; q4[h] = *(const f32x4*)(qks + h * D + 4 * lane); d4[h] = *(const f32x4*)(dct + h * D + 4 * lane); }
         T* const dxb = (T*)p.dX + (size_t)n * Tn * D;
-        for (int t0 = w; t0 < Tn; t0 += 16) {
-            f32x4 xv[4];
+        for (int t0 = w; t0 < Tn; t0 += 32) {
+            f32x4 xv[8];
+            rows8<T>(xv, xb, Tn, lane, t0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int t = t0 + 4 * u; xv[u] = t < Tn ? load4(xb + (size_t)t * D + 4 * lane) : f32x4{0, 0, 0, 0}; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int t = t0 + 4 * u;
                 if (t < Tn) {
                     f32x4 o = f32x4{0, 0, 0, 0};
@@ -280,40 +294,52 @@ __global__ void __launch_bounds__(256) attn_last_bwd_kernel(const AttnLastArgs p
         p.dqk[((size_t)n * 4 + h) * D + c] = v;
     }
     __syncthreads();
-    {   // dq0[64 w + j] = Wk[64 w + j] . dqk_w
-        const float r = w < p.H ? attn_last::rows_dot<T>((const T*)p.Wk, qks + w * D, w, lane) : 0.0f;
-        dq0s[64 * w + lane] = r;
-        ((T*)p.dq0)[(size_t)n * D + 64 * w + lane] = from_f32<T>(r);
-    }
+    // dq0[64 w + j] = Wk[64 w + j] . dqk_w
+    if (w < p.H) attn_last::rows_mfma<T>((const T*)p.Wk, qks + w * D, dq0s, w, lane);
+    else dq0s[c] = 0.0f;
     __syncthreads();
-    {   // frame 0 also carries the residual path and the query: dx_0 += dpre + Wq^T dq0
-        float a = row0[c] + to_f32(((const T*)p.dpre)[(size_t)n * D + c]);
-        const T* wq = (const T*)p.Wq + c;
-#pragma unroll 8
-        for (int j = 0; j < 256; ++j) a += dq0s[j] * to_f32(wq[(size_t)j * D]);
+    ((T*)p.dq0)[(size_t)n * D + c] = from_f32<T>(dq0s[c]);
+    // frame 0 also carries the residual path and the query: dx_0 += dpre + Wq^T dq0 (wave w sums rows 64 w .. 64 w + 63 of Wq)
+    *(f32x4*)(red + w * D + 4 * lane) = attn_last::cols_dot<T>((const T*)p.Wq, dq0s, w, lane);
+    __syncthreads();
+    {
+        const float a = row0[c] + to_f32(((const T*)p.dpre)[(size_t)n * D + c]) + (red[c] + red[D + c]) + (red[2 * D + c] + red[3 * D + c]);
         ((T*)p.dX)[(size_t)n * Tn * D + c] = from_f32<T>(a);
     }
 }
 
 // dWk[r][c] += sum_n q0[n][r] dqk[n][r / 64][c],  dWv[r][c] += sum_n do[n][r] ctx[n][r / 64][c],  dbv[r] += sum_n do[n][r] sp[n][r / 64]
-// grid = (512, chunks): blockIdx.x < 256 the Wk rows, >= 256 the Wv rows; blockIdx.y a slice of the utterances
+// grid = (128, chunks): block b < 64 takes rows 4 b .. 4 b + 3 of Wk, b >= 64 the same rows of Wv (one head: one B row feeds four output
+// rows); blockIdx.y a slice of the utterances; thread = column
 template <typename T>
 __global__ void __launch_bounds__(256) attn_last_wgrad_kernel(const void* q0, const float* dqk, const void* do0, const float* ctx,
                                                               const float* sp, float* dWk, float* dWv, float* dbv, int N, int per) {
     __shared__ float red[4];
-    const int r = blockIdx.x & 255, isv = blockIdx.x >> 8, h = r >> 6, c = threadIdx.x;
-    const T* const a = (const T*)(isv ? do0 : q0) + r;
+    const int isv = blockIdx.x >> 6, r0 = (blockIdx.x & 63) * 4, h = r0 >> 6, c = threadIdx.x;
+    const T* const a = (const T*)(isv ? do0 : q0) + r0;
     const float* const B = (isv ? ctx : dqk) + (size_t)h * 256 + c;
     const int n0 = blockIdx.y * per, n1 = min(N, n0 + per);
-    float acc = 0.0f;
-#pragma unroll 4
-    for (int n = n0; n < n1; ++n) acc += to_f32(a[(size_t)n * 256]) * B[(size_t)n * 1024];
-    atomicAdd((isv ? dWv : dWk) + (size_t)r * 256 + c, acc);
+    f32x4 acc = f32x4{0, 0, 0, 0};
+    int n = n0;
+    for (; n + 8 <= n1; n += 8) {
+        float b[8]; f32x4 av[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { b[u] = B[(size_t)(n + u) * 1024]; av[u] = load4(a + (size_t)(n + u) * 256); }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += b[u] * av[u];
+    }
+    for (; n < n1; ++n) acc += B[(size_t)n * 1024] * load4(a + (size_t)n * 256);
+    float* const dW = (isv ? dWv : dWk) + (size_t)r0 * 256 + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dW + r * 256, acc[r]);
     if (isv) {
-        float b = 0.0f;
-        for (int n = n0 + c; n < n1; n += 256) b += to_f32(a[(size_t)n * 256]) * sp[(size_t)n * 4 + h];
-        b = block256_sum(b, red);
-        if (c == 0) atomicAdd(dbv + r, b);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float b = 0.0f;
+            for (int m = n0 + c; m < n1; m += 256) b += to_f32(a[(size_t)m * 256 + r]) * sp[(size_t)m * 4 + h];
+            b = block256_sum(b, red);
+            if (c == 0) atomicAdd(dbv + r0 + r, b);
+        }
     }
 }
 

@@ -1086,9 +1086,9 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             forked_after_dh = true;
             {   // k | v rows of in_proj_weight (and the v bias; the k bias has no gradient: its score term is constant over the frames)
                 auto kern = attn_last_wgrad_kernel<T>;
-                const int chunks = std::max(1, std::min(8, n / 64)), per = (n + chunks - 1) / chunks;
+                const int chunks = std::max(1, std::min(16, n / 32)), per = (n + chunks - 1) / chunks;
                 float* const dW = G(lp(l, L_IN_W));
-                GE2E_LAUNCH(h, kern, dim3(512, chunks), dim3(256), 0, wst, (const void*)(ws + L.lq0), (const float*)(ws + L.ldqk), (const void*)b_dO,
+                GE2E_LAUNCH(h, kern, dim3(128, chunks), dim3(256), 0, wst, (const void*)(ws + L.lq0), (const float*)(ws + L.ldqk), (const void*)b_dO,
                             (const float*)(ws + L.lctx), (const float*)(ws + L.lsp), dW + (size_t)d * d, dW + (size_t)2 * d * d, G(lp(l, L_IN_B)) + 2 * d, n, per);
             }
             WgradArgs wq{};   // q rows from frame 0 of every utterance

@@ -122,8 +122,17 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
         prob = torch.softmax(s, dim=-1)
         keep_a = torch.from_numpy(O.drop_keep_at(O.drop_key(seed, 0, O.site_attn(l)), O.attn_drop_index(n, heads, t), p)).to(F64)
         if last:
-            pd0 = prob[:, :, 0, :] * keep_a[:, :, 0, :] * scale_d                                  # fp32 vector kernel: P is not rounded
-            o_ref = torch.einsum("nhk,nhkd->nhd", pd0, v).reshape(n, d)
+            # attn_last.cuh: one query per (utterance, head), no K / V.  qk_h = Wk_h^T q0_h and ctx_h = sum_t pd_t x_t are the operands of
+            # matrix-pipe products, so they are rounded to the storage type; the probabilities stay fp32
+            Wi, bi = W[pre + "self_attn.in_proj_weight"], Pf[pre + "self_attn.in_proj_bias"]
+            q0h = qkv[rows0, :d].reshape(n, heads, 64)
+            qk = rt(torch.einsum("nhj,hjc->nhc", q0h, Wi[d:2 * d].reshape(heads, 64, d)), prec)
+            xin = h_in.reshape(n, t, d)
+            prob0 = torch.softmax(torch.einsum("nhc,ntc->nht", qk, xin) / 8.0, dim=-1)
+            pd0 = prob0 * keep_a[:, :, 0, :] * scale_d
+            ctx = rt(torch.einsum("nht,ntc->nhc", pd0, xin), prec)
+            o_ref = (torch.einsum("nhc,hjc->nhj", ctx, Wi[2 * d:].reshape(heads, 64, d))
+                     + bi[2 * d:].reshape(1, heads, 64) * pd0.sum(-1, keepdim=True)).reshape(n, d)
         else:
             pd = rt(prob * keep_a * scale_d, prec)                                                 # P is packed to the storage type for P.V
             o_ref = (pd @ v).permute(0, 2, 1, 3).reshape(R, d)
