@@ -257,7 +257,7 @@ def main():
         emb = model(batches[i & 1] if host is None else fetch(i))
         loss = criterion(emb, P)
         optimizer.zero_grad()
-        scaler.scale(loss).backward()
+        scaler.backward(loss)                # = scaler.scale(loss).backward(), as Trainer.Train_Step issues it
         scaler.unscale_(optimizer)
         scaler.step(optimizer)               # (un)scale + inf check + clip + AdamW (+ scale update), fused: Trainer.Train_Step's calls
         scaler.update()

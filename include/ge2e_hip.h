@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE2E_ABI_VERSION 2
+#define GE2E_ABI_VERSION 3
 
 enum {
     GE2E_OK = 0,
@@ -128,9 +128,11 @@ int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int 
 size_t ge2e_loss_workspace_bytes(int speakers, int utts, int emb);
 int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
                       float w, float b, float* loss, void* loss_ws, size_t loss_ws_bytes);
-/* d_loss: device fp32 scalar (upstream gradient); d_emb: device fp32 [speakers*utts, emb] */
+/* d_loss: device fp32 scalar (upstream gradient); d_emb: device fp32 [speakers*utts, emb]; d_weight_bias: device fp32 [2] receiving
+ * dL/dw and dL/db of the criterion's own parameters (reference Modules.py:115-116: nn.Parameters that autograd fills although
+ * nothing ever optimises them, Train.py:121-127), or NULL.  (dL/db is zero up to rounding: a shift of all logits of a row.) */
 int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
-                       float w, float b, const float* d_loss, float* d_emb, void* loss_ws, size_t loss_ws_bytes);
+                       float w, float b, const float* d_loss, float* d_emb, float* d_weight_bias, void* loss_ws, size_t loss_ws_bytes);
 
 /* clip_grad_norm_(max_norm) followed by one torch.optim.AdamW step (reference Train.py:154-162) over `count`
  * parameter tensors, fused into two launches.  params/grads/exp_avg/exp_avg_sq: HOST arrays of device pointers

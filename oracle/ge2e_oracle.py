@@ -388,8 +388,9 @@ def loss_forward(emb, pattern_per_speaker, w=10.0, b=-5.0):
     return dt.type(loss), cache
 
 
-def loss_backward(c, d_loss=1.0):
-    """SURVEY.md Appendix A matrix form (checked there against reference autograd in fp64)."""
+def loss_backward(c, d_loss=1.0, with_wb=False):
+    """SURVEY.md Appendix A matrix form (checked there against reference autograd in fp64).  with_wb: also the gradients of the
+    criterion's own weight / bias (Modules.py:115-116; sim = w cos - b): dL/dw = sum (softmax - onehot) cos / N, dL/db = -sum(...) = 0."""
     emb, cent, en, cn, cos = c["emb"], c["cent"], c["en"], c["cn"], c["cos"]
     dt = emb.dtype
     n, d = emb.shape
@@ -403,7 +404,11 @@ def loss_backward(c, d_loss=1.0):
     chat = cent / cn
     direct = (G @ chat) / en - (G * cos).sum(-1, keepdims=True) * emb / (en * en)
     dC = (G.T @ ehat) / cn - (G * cos).sum(0)[:, None] * cent / (cn * cn)
-    return (direct + np.repeat(dC, P, axis=0) / dt.type(P)).astype(dt)
+    d_emb = (direct + np.repeat(dC, P, axis=0) / dt.type(P)).astype(dt)
+    if not with_wb:
+        return d_emb
+    G0 = G.astype(np.float64) / float(c["w"])
+    return d_emb, float((G0 * cos).sum()), float(-G0.sum())
 
 
 # --------------------------------------------------------------------------------------

@@ -279,7 +279,7 @@ class GE2E(torch.nn.Module):
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, embeddings, pattern_per_speaker):
+    def forward(ctx, module, embeddings, pattern_per_speaker, weight, bias):
         _require_gpu(embeddings, "embeddings")
         emb = embeddings.contiguous().float()
         n, d = emb.shape
@@ -303,17 +303,22 @@ class _LossFn(torch.autograd.Function):
         speakers, utts, w, b = ctx.dims
         hnd = ctx.module._handle(emb.shape[1], emb.device)
         d_emb = torch.empty_like(emb)
+        # the criterion's own weight / bias (reference Modules.py:115-116): autograd fills their .grad there, so it does here
+        want_wb = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        d_wb = torch.empty(2, device=emb.device, dtype=torch.float32) if want_wb else None
         with torch.cuda.device(emb.device):
             stream = torch.cuda.current_stream(emb.device).cuda_stream
-            hnd.loss_backward(stream, emb, speakers, utts, w, b, d_loss.reshape(1).contiguous().float(), d_emb, ctx.ws)
-        return None, d_emb, None
+            hnd.loss_backward(stream, emb, speakers, utts, w, b, d_loss.reshape(1).contiguous().float(), d_emb, ctx.ws, d_wb)
+        return (None, d_emb, None, d_wb[0].reshape(()) if ctx.needs_input_grad[3] else None,
+                d_wb[1].reshape(()) if ctx.needs_input_grad[4] else None)
 
 
 class GE2E_Loss(torch.nn.Module):
     """GE2E softmax loss with self-inclusive centroids and logits w*cos - b (Modules.py:112-156).
 
-    `weight`/`bias` stay nn.Parameters for API parity, but exactly as in the reference they are never
-    optimised, all-reduced or checkpointed (Train.py:121-127,298-303), so no gradient is produced for them.
+    `weight`/`bias` are nn.Parameters as in the reference: never optimised, all-reduced or checkpointed there
+    (Train.py:121-127,298-303), but autograd fills their `.grad`, and so does the HIP backward (two scalar sums that ride in the
+    row kernel); `requires_grad_(False)` on them skips that.
     """
 
     def __init__(self, init_weight=10.0, init_bias=-5.0):
@@ -339,7 +344,7 @@ class GE2E_Loss(torch.nn.Module):
 
     def forward(self, embeddings, pattern_per_speaker):
         """embeddings: [Batch, Emb_dim], speaker-major (Datasets.Collater order); returns a 0-d loss."""
-        return _LossFn.apply(self, embeddings, int(pattern_per_speaker))
+        return _LossFn.apply(self, embeddings, int(pattern_per_speaker), self.weight, self.bias)
 
 
 class _GatherBatchFn(torch.autograd.Function):

@@ -41,6 +41,17 @@ class GradScaler:
             return loss
         return loss * self.state(loss.device)[0]
 
+    def backward(self, loss):
+        """`scale(loss).backward()` without the two elementwise launches it costs (the multiply and autograd's ones_like root): the
+        loss scale -- or a cached 1 -- is handed to backward as the upstream gradient, a device scalar the HIP loss backward reads."""
+        if self._enabled:
+            g = self.state(loss.device)[0]
+        else:
+            if getattr(self, "_one", None) is None or self._one.device != loss.device:
+                self._one = torch.ones((), device=loss.device, dtype=torch.float32)
+            g = self._one
+        loss.backward(gradient=g.reshape(loss.shape))
+
     def unscale_(self, optimizer):
         """Accepted for call-pattern parity: the unscale is fused into step()."""
         return None

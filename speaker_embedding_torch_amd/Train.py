@@ -120,7 +120,7 @@ class Trainer:
         embeddings = self.model(features)
         loss = self.criterion(embeddings, self.hp.Train.Batch.Train.Pattern_per_Speaker)
         self.optimizer.zero_grad()
-        self.scaler.scale(loss).backward()   # HIP backward; gradient buckets all-reduced as they complete
+        self.scaler.backward(loss)           # = scaler.scale(loss).backward() (Train.py:153); HIP backward, buckets all-reduced as they complete
         self.scaler.unscale_(self.optimizer)
         self.scaler.step(self.optimizer)     # unscale + inf check + clip_grad_norm_(Gradient_Norm) + AdamW, fused (Train.py:154-162)
         self.scaler.update()

@@ -14,7 +14,7 @@ BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
-ABI_VERSION = 2
+ABI_VERSION = 3
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD, K_FFN = 1, 2, 4, 8, 16, 32, 64
 FWD_PREPARED = 2       # ge2e_encoder_forward's `train` argument: eval forward, weight copies already in the workspace
 K_SERIAL = 1 << 30      # with a class bit: the backward keeps its weight gradients on the caller's stream (kernels timed alone)
@@ -58,7 +58,7 @@ _SIG = {
     "ge2e_loss_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_size_t]),
     "ge2e_loss_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float,
-                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "ge2e_clip_adamw_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_void_p,
                                        C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64]),
@@ -179,9 +179,10 @@ class Handle:
         self.check(self.lib.ge2e_loss_forward(self._h, stream, emb.data_ptr(), speakers, utts, w, b, loss.data_ptr(),
                                               ws.data_ptr(), ws.numel() * ws.element_size()), "ge2e_loss_forward")
 
-    def loss_backward(self, stream, emb, speakers, utts, w, b, d_loss, d_emb, ws):
+    def loss_backward(self, stream, emb, speakers, utts, w, b, d_loss, d_emb, ws, d_wb=None):
         self.check(self.lib.ge2e_loss_backward(self._h, stream, emb.data_ptr(), speakers, utts, w, b, d_loss.data_ptr(),
-                                               d_emb.data_ptr(), ws.data_ptr(), ws.numel() * ws.element_size()),
+                                               d_emb.data_ptr(), d_wb.data_ptr() if d_wb is not None else None,
+                                               ws.data_ptr(), ws.numel() * ws.element_size()),
                    "ge2e_loss_backward")
 
     def clip_adamw_step(self, stream, ptrs_p, ptrs_g, ptrs_m, ptrs_v, numel, norm, max_norm, lr, b1, b2, eps, wd, step):

@@ -493,11 +493,18 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             // shows for the two rows together
             {
                 ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R32 * (double)a.N * a.K, (double)R32 * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
+                static const bool atomic = getenv("GE2E_WGRAD_KS_ATOMIC") != nullptr;
+                k.dW = a.dW; k.ldw = a.ldw;
+                if (atomic) {
+                    auto kern = wgrad_ks_kernel<T, true>;
+                    GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
+                } else {
                 auto kern = wgrad_ks_kernel<T>;
                 GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
                 // split groups: ~256 reduce blocks whatever the tile count (a single-tile product used to sum its 160 partials in 64 blocks)
                 const int sgroups = std::max(1, std::min(splits, 256 / (ntile * 32)));
                 GE2E_LAUNCH(h, wgrad_ks_reduce_kernel, dim3(ntile * 32, sgroups), dim3(512), 0, st, (const float*)part, a.dW, a.ldw, splits, tn, tk);
+                }
             }
             if (R32 == a.R) return 0;
             WgradArgs tail = a;                                          // < 32 rows left: the tiled kernel adds them atomically
@@ -1121,14 +1128,17 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again
 }
 
-struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, total; };
+struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, total; int Y; };
+// slices of the utterances in the centroid-gradient pass (one partial slab each): ~60 rows per block, bounded so that the slabs stay small
+inline int loss_slices(int S, int N) { return std::max(1, std::min(std::min(16, 2048 / std::max(S, 1)), N / 48)); }
 LossLayout loss_layout(int S, int P, int d) {
     LossLayout L{};
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += (floats * 4 + 255) / 256 * 256; return o; };
     const size_t N = (size_t)S * P;
     L.cent = take((size_t)S * d); L.cn = take(S); L.en = take(N); L.rowloss = take(N);
-    L.G = take(N * S); L.cosm = take(N * S); L.dC = take((size_t)S * d);
+    L.Y = loss_slices(S, (int)N);
+    L.G = take(N * S); L.cosm = take(N * S); L.dC = take((size_t)L.Y * S * d);
     L.total = off;
     return L;
 }
@@ -1136,7 +1146,7 @@ LossArgs loss_args(const float* emb, int S, int P, float w, float b, unsigned ch
     LossArgs a{};
     a.emb = emb; a.N = S * P; a.S = S; a.P = P; a.w = w; a.b = b;
     a.cent = (float*)(ws + L.cent); a.cn = (float*)(ws + L.cn); a.en = (float*)(ws + L.en);
-    a.rowloss = (float*)(ws + L.rowloss); a.G = (float*)(ws + L.G); a.cosm = (float*)(ws + L.cosm); a.dC = (float*)(ws + L.dC);
+    a.rowloss = (float*)(ws + L.rowloss); a.G = (float*)(ws + L.G); a.cosm = (float*)(ws + L.cosm); a.dC = (float*)(ws + L.dC); a.Y = L.Y;
     return a;
 }
 
@@ -1274,12 +1284,11 @@ int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speaker
     a.loss = loss;
     GE2E_LAUNCH(h, loss_centroid_kernel, dim3(speakers), dim3(256), 0, st, a);
     GE2E_LAUNCH(h, loss_row_kernel, dim3(a.N), dim3(256), (size_t)2 * speakers * 4, st, a);
-    GE2E_LAUNCH(h, loss_reduce_kernel, dim3(1), dim3(256), 0, st, a);
     return 0;
 }
 
 int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speakers, int utts,
-                       float w, float b, const float* d_loss, float* d_emb, void* loss_ws, size_t loss_ws_bytes) {
+                       float w, float b, const float* d_loss, float* d_emb, float* d_weight_bias, void* loss_ws, size_t loss_ws_bytes) {
     if (!h) return GE2E_EINVAL;
     if (!emb || !d_loss || !d_emb || !loss_ws || speakers <= 0 || utts <= 0) return fail(h, GE2E_EINVAL, "loss: bad argument");
     const LossLayout L = loss_layout(speakers, utts, h->cfg.emb);
@@ -1287,10 +1296,8 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     CK(check_device(h));
     hipStream_t st = (hipStream_t)stream;
     LossArgs a = loss_args(emb, speakers, utts, w, b, (unsigned char*)loss_ws, L);
-    a.gscale = d_loss; a.d_emb = d_emb;
-    hipError_t em = hipMemsetAsync(a.dC, 0, (size_t)speakers * h->cfg.emb * 4, st);
-    if (em != hipSuccess) return fail_hip(h, em, "zero dC");
-    GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers, std::max(1, std::min(32, (a.N + 31) / 32))), dim3(256), 0, st, a);
+    a.gscale = d_loss; a.d_emb = d_emb; a.dwb = d_weight_bias;
+    GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers, a.Y), dim3(256), 0, st, a);
     GE2E_LAUNCH(h, loss_bwd_row_kernel, dim3(a.N), dim3(256), 0, st, a);
     return 0;
 }

@@ -320,15 +320,19 @@ __global__ void __launch_bounds__(256) tail_wgrad_kernel(const TailArgs p) {
 struct LossArgs {
     const float* emb; int N, S, P;
     float w, b;
-    float* cent; float* cn; float* en; float* rowloss; float* G; float* cosm; float* dC;
+    float* cent; float* cn; float* en; float* rowloss; float* G; float* cosm;
+    float* dC; int Y;            // [Y][S][256] partial centroid gradients, one slab per slice of the utterances (plain stores: no zeroing, no atomics)
     float* loss;                 // [1]
     const float* gscale;         // device scalar dL/dloss (backward)
     float* d_emb;                // [N,256]
+    float* dwb;                  // [2] dL/dw, dL/db of the criterion's own parameters (reference Modules.py:115-116), or null
 };
 
+// (block 0 also zeroes the loss accumulator the row kernel adds into)
 __global__ void __launch_bounds__(256) loss_centroid_kernel(const LossArgs p) {
     __shared__ float red[4];
     const int s = blockIdx.x, c = threadIdx.x;
+    if (s == 0 && c == 0) p.loss[0] = 0.0f;
     float acc = 0.0f;
     for (int q = 0; q < p.P; ++q) acc += p.emb[((size_t)s * p.P + q) * 256 + c];
     acc /= (float)p.P;
@@ -337,6 +341,8 @@ __global__ void __launch_bounds__(256) loss_centroid_kernel(const LossArgs p) {
     if (c == 0) p.cn[s] = nn;
 }
 
+// one block per utterance: cosines against every centroid, softmax cross-entropy, G0 = (softmax - onehot) / N (= dL/dsim); the row's
+// loss / N is added to the scalar (960 float atomics on one word: their order moves the last bit of the printed loss, nothing else)
 __global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sims = (float*)smem;             // [S]
@@ -361,29 +367,27 @@ __global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
         for (int s = lane; s < p.S; s += 64) sum += expf(sims[s] - mx);
         sum = wave_sum(sum);
         const float lse = mx + logf(sum);
-        if (lane == 0) { bc[0] = lse; p.rowloss[irow] = lse - sims[own]; p.en[irow] = en; }
+        if (lane == 0) {
+            bc[0] = lse; p.en[irow] = en;
+            const float rl = lse - sims[own];
+            p.rowloss[irow] = rl;
+            atomicAdd(p.loss, rl / (float)p.N);
+        }
     }
     __syncthreads();
     const float lse = bc[0];
-    const float k = p.w / (float)p.N;
+    const float k = 1.0f / (float)p.N;
     for (int s = threadIdx.x; s < p.S; s += 256) {
         p.G[(size_t)irow * p.S + s] = (expf(sims[s] - lse) - (s == own ? 1.0f : 0.0f)) * k;
         p.cosm[(size_t)irow * p.S + s] = coss[s];
     }
 }
 
-__global__ void __launch_bounds__(256) loss_reduce_kernel(const LossArgs p) {
-    __shared__ float red[4];
-    float acc = 0.0f;
-    for (int q = threadIdx.x; q < p.N; q += 256) acc += p.rowloss[q];
-    const float t = block256_sum(acc, red);
-    if (threadIdx.x == 0) p.loss[0] = t / (float)p.N;
-}
-
-// dC[s][c] += (sum_i G[i][s] ehat_i[c]) / cn_s - (sum_i G[i][s] cos[i][s]) c_s[c] / cn_s^2 over this block's slice
-// of utterances (the expression is linear in the two sums, so slices combine by atomics on a zeroed dC).
+// dC_y[s][c] = w ((sum_i G0[i][s] ehat_i[c]) / cn_s - (sum_i G0[i][s] cos[i][s]) c_s[c] / cn_s^2) over slice y of the utterances: the expression
+// is linear in the two sums, so the row kernel adds the Y slabs.  grid = (S, Y)
 __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p) {
     const int s = blockIdx.x, c = threadIdx.x;
+    if (p.dwb && s == 0 && blockIdx.y == 0 && c < 2) p.dwb[c] = 0.0f;      // the row kernel (next launch) adds into it
     const int per = (p.N + gridDim.y - 1) / gridDim.y, q0 = blockIdx.y * per, q1 = min(p.N, q0 + per);
     float a = 0.0f, gc = 0.0f;
 #pragma unroll 4
@@ -393,21 +397,25 @@ __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p
         gc += g * p.cosm[(size_t)q * p.S + s];
     }
     const float cn = p.cn[s];
-    atomicAdd(p.dC + (size_t)s * 256 + c, a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn));
+    p.dC[((size_t)blockIdx.y * p.S + s) * 256 + c] = p.w * (a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn));
 }
 
-// d_emb_i = gscale * ( (G_i chat)/en_i - (G_i . cos_i) e_i / en_i^2 + dC[spk(i)] / P )
+// d_emb_i = gscale * ( w (G0_i chat)/en_i - w (G0_i . cos_i) e_i / en_i^2 + dC[spk(i)] / P );   dL/dw += gscale G0_i . cos_i,  dL/db -= gscale sum_s G0[i][s]
 __global__ void __launch_bounds__(256) loss_bwd_row_kernel(const LossArgs p) {
     const int irow = blockIdx.x, c = threadIdx.x;
-    float a = 0.0f, gc = 0.0f;
+    float a = 0.0f, gc = 0.0f, gs = 0.0f;
     for (int s = 0; s < p.S; ++s) {
         const float g = p.G[(size_t)irow * p.S + s];
         a += g * p.cent[(size_t)s * 256 + c] / p.cn[s];
         gc += g * p.cosm[(size_t)irow * p.S + s];
+        gs += g;
     }
-    const float en = p.en[irow];
-    const float v = a / en - gc * p.emb[(size_t)irow * 256 + c] / (en * en) + p.dC[(size_t)(irow / p.P) * 256 + c] / (float)p.P;
-    p.d_emb[(size_t)irow * 256 + c] = v * p.gscale[0];
+    float dc = 0.0f;
+    for (int y = 0; y < p.Y; ++y) dc += p.dC[((size_t)y * p.S + irow / p.P) * 256 + c];
+    const float en = p.en[irow], gsc = p.gscale[0];
+    const float v = p.w * (a / en - gc * p.emb[(size_t)irow * 256 + c] / (en * en)) + dc / (float)p.P;
+    p.d_emb[(size_t)irow * 256 + c] = v * gsc;
+    if (p.dwb && c == 0) { atomicAdd(p.dwb, gc * gsc); atomicAdd(p.dwb + 1, -gs * gsc); }
 }
 
 // ---------------------------------------------------------------------------------------------

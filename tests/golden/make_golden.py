@@ -133,18 +133,23 @@ def main():
         e = e + 2.0 * np.repeat(O.formula_normal(60 + tag, (s, 256)), p, axis=0)
         e = (e / np.linalg.norm(e, axis=1, keepdims=True)).astype(np.float32)
         et = torch.from_numpy(e).requires_grad_(True)
+        crit.zero_grad()
         l = crit(et, p)
         l.backward()
         out[f"G6_loss_{s}x{p}"] = np.array([l.item()], np.float32)
         gr = et.grad.numpy()
         out[f"G6_demb_norm_{s}x{p}"] = np.array([np.linalg.norm(gr.astype(np.float64))])
         out[f"G6_demb_head_{s}x{p}"] = gr[:4].copy()
+        # G8: the criterion's own parameters (Modules.py:115-116): autograd fills weight.grad / bias.grad although nothing optimises them
+        out[f"G8_dw_db_{s}x{p}"] = np.array([crit.weight.grad.item(), crit.bias.grad.item()], np.float64)
     # un-normalised embeddings exercise the norm clamps / general cosine path
     e = O.formula_normal(70, (12, 256)).astype(np.float32) * 0.3
     et = torch.from_numpy(e).requires_grad_(True)
+    crit.zero_grad()
     l = crit(et, 4); l.backward()
     out["G6_loss_unnorm_3x4"] = np.array([l.item()], np.float32)
     out["G6_demb_unnorm_3x4"] = et.grad.numpy().copy()
+    out["G8_dw_db_unnorm_3x4"] = np.array([crit.weight.grad.item(), crit.bias.grad.item()], np.float64)
 
     np.savez_compressed(os.path.join(OUT, "ge2e_golden.npz"), **out)
     sz = os.path.getsize(os.path.join(OUT, "ge2e_golden.npz"))

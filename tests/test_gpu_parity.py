@@ -102,9 +102,13 @@ def test_loss_matches_reference_goldens(mods, golden, tag, s, p):
     e = e + 2.0 * np.repeat(O.formula_normal(60 + tag, (s, 256)), p, axis=0)
     e = (e / np.linalg.norm(e, axis=1, keepdims=True)).astype(np.float32)
     et = torch.from_numpy(e).cuda().requires_grad_(True)
-    loss = GE2E_Loss().cuda()(et, p)
+    crit = GE2E_Loss().cuda()
+    loss = crit(et, p)
     loss.backward()
     assert abs(loss.item() - float(golden[f"G6_loss_{s}x{p}"][0])) < 1e-5
+    # G8: the criterion's own weight / bias gradients as the reference's autograd fills them (Modules.py:115-116); dL/db is 0 up to rounding
+    dw_ref, db_ref = golden[f"G8_dw_db_{s}x{p}"]
+    assert abs(crit.weight.grad.item() - dw_ref) < 1e-4 * abs(dw_ref) + 1e-8 and abs(crit.bias.grad.item() - db_ref) < 1e-6
     g = et.grad.cpu().numpy()
     ref_norm = float(golden[f"G6_demb_norm_{s}x{p}"][0])
     assert abs(np.linalg.norm(g.astype(np.float64)) - ref_norm) < 1e-3 * ref_norm
@@ -115,9 +119,16 @@ def test_loss_unnormalised_and_upstream_scale(mods, golden):
     _, GE2E_Loss = mods
     e = O.formula_normal(70, (12, 256)).astype(np.float32) * np.float32(0.3)
     et = torch.from_numpy(e).cuda().requires_grad_(True)
-    loss = GE2E_Loss().cuda()(et, 4)
+    crit = GE2E_Loss().cuda()
+    loss = crit(et, 4)
     (loss * 3.0).backward()                     # upstream gradient is read on the device
     assert abs(loss.item() - float(golden["G6_loss_unnorm_3x4"][0])) < 1e-5
+    dw_ref, db_ref = golden["G8_dw_db_unnorm_3x4"]
+    assert abs(crit.weight.grad.item() / 3.0 - dw_ref) < 1e-4 * abs(dw_ref) and abs(crit.bias.grad.item()) < 1e-6
+    frozen = GE2E_Loss().cuda()
+    frozen.weight.requires_grad_(False); frozen.bias.requires_grad_(False)
+    frozen(et.detach().requires_grad_(True), 4).backward()
+    assert frozen.weight.grad is None and frozen.bias.grad is None
     assert rel_l2(et.grad.cpu().numpy() / 3.0, golden["G6_demb_unnorm_3x4"]) < 1e-3
 
 

@@ -106,6 +106,10 @@ def test_G6_loss_only(golden, tag, s, p):
     # unit-norm inputs make d_emb a difference of nearly equal terms: fp32 cancellation in the
     # reference itself limits agreement to ~1e-3 of the largest component
     assert np.abs(g[:4] - golden[f"G6_demb_head_{s}x{p}"]).max() < 2e-3 * np.abs(golden[f"G6_demb_head_{s}x{p}"]).max()
+    # G8: gradients of the criterion's own weight / bias (reference Modules.py:115-116, filled by its autograd)
+    _, dw, db = O.loss_backward(lc, with_wb=True)
+    dw_ref, db_ref = golden[f"G8_dw_db_{s}x{p}"]
+    assert abs(dw - dw_ref) < 1e-4 * abs(dw_ref) + 1e-8 and abs(db - db_ref) < 1e-6
 
 
 def test_G6_loss_unnormalised(golden):
