@@ -198,6 +198,8 @@ def main():
     torch.manual_seed(0)                       # same initial weights on every rank (then broadcast anyway)
     model = GE2E(hp, precision=args.precision, seed=1234 + rank).to(dev)
     criterion = GE2E_Loss().to(dev)
+    for p_ in criterion.parameters():          # as Trainer.Model_Generate: never optimised, their .grad would only be accumulated
+        p_.requires_grad_(False)
     if use_dist:
         model = apply_gradient_allreduce(model)
     optimizer = FusedClipAdamW(model.parameters(), lr=hp.Train.Learning_Rate.Initial,

@@ -100,6 +100,11 @@ class Trainer:
         # optional key Train.Global_Batch_Loss (default off = the reference's per-rank loss)
         global_loss = bool(getattr(self.hp.Train, "Global_Batch_Loss", False)) and self.num_gpus > 1
         self.criterion = (GE2E_Loss_Global() if global_loss else GE2E_Loss()).to(self.device)
+        # The criterion's weight / bias are nn.Parameters nothing optimises, reduces or saves (Train.py:121-127,298-303); with requires_grad
+        # their .grad would be accumulated every step (three small launches on the step's critical path) and never read: switched off HERE,
+        # not in the module (GE2E_Loss itself produces them like the reference's autograd does)
+        for p_ in self.criterion.parameters():
+            p_.requires_grad_(False)
         # torch.optim.AdamW semantics and state_dict (incl. the default weight_decay 0.01 the reference ends up with,
         # Train.py:122-127), with clip_grad_norm_(Gradient_Norm) fused into the same two device launches
         self.optimizer = FusedClipAdamW(

@@ -893,8 +893,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     auto bucket = [&](int first, int last) {   // parameters [first, last] are final: tell the caller
         if (cb) cb(user, h->params[first].offset, h->params[last].offset + h->params[last].numel - h->params[first].offset);
     };
-    hipError_t e = hipMemsetAsync(grads, 0, (size_t)h->total * 4, st);
-    if (e != hipSuccess) return fail_hip(h, e, "zero grads");
+    if (((uintptr_t)grads & 15) != 0) return fail(h, GE2E_EINVAL, "grads_flat must be 16-byte aligned");
+    GE2E_LAUNCH(h, zero_f32_kernel, dim3(512), dim3(256), 0, st, grads, (size_t)h->total);
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
     // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
@@ -1128,7 +1128,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again
 }
 
-struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, total; int Y; };
+struct LossLayout { size_t cent, cn, en, rowloss, G, cosm, dC, rowwb, total; int Y; };
 // slices of the utterances in the centroid-gradient pass (one partial slab each): ~60 rows per block, bounded so that the slabs stay small
 inline int loss_slices(int S, int N) { return std::max(1, std::min(std::min(16, 2048 / std::max(S, 1)), N / 48)); }
 LossLayout loss_layout(int S, int P, int d) {
@@ -1138,7 +1138,7 @@ LossLayout loss_layout(int S, int P, int d) {
     const size_t N = (size_t)S * P;
     L.cent = take((size_t)S * d); L.cn = take(S); L.en = take(N); L.rowloss = take(N);
     L.Y = loss_slices(S, (int)N);
-    L.G = take(N * S); L.cosm = take(N * S); L.dC = take((size_t)L.Y * S * d);
+    L.G = take(N * S); L.cosm = take(N * S); L.dC = take((size_t)L.Y * S * d); L.rowwb = take(2 * N);
     L.total = off;
     return L;
 }
@@ -1146,7 +1146,7 @@ LossArgs loss_args(const float* emb, int S, int P, float w, float b, unsigned ch
     LossArgs a{};
     a.emb = emb; a.N = S * P; a.S = S; a.P = P; a.w = w; a.b = b;
     a.cent = (float*)(ws + L.cent); a.cn = (float*)(ws + L.cn); a.en = (float*)(ws + L.en);
-    a.rowloss = (float*)(ws + L.rowloss); a.G = (float*)(ws + L.G); a.cosm = (float*)(ws + L.cosm); a.dC = (float*)(ws + L.dC); a.Y = L.Y;
+    a.rowloss = (float*)(ws + L.rowloss); a.G = (float*)(ws + L.G); a.cosm = (float*)(ws + L.cosm); a.dC = (float*)(ws + L.dC); a.Y = L.Y; a.rowwb = (float*)(ws + L.rowwb);
     return a;
 }
 
@@ -1284,6 +1284,7 @@ int ge2e_loss_forward(ge2e_handle h, void* stream, const float* emb, int speaker
     a.loss = loss;
     GE2E_LAUNCH(h, loss_centroid_kernel, dim3(speakers), dim3(256), 0, st, a);
     GE2E_LAUNCH(h, loss_row_kernel, dim3(a.N), dim3(256), (size_t)2 * speakers * 4, st, a);
+    GE2E_LAUNCH(h, loss_reduce_kernel, dim3(1), dim3(256), 0, st, a);
     return 0;
 }
 
@@ -1299,6 +1300,7 @@ int ge2e_loss_backward(ge2e_handle h, void* stream, const float* emb, int speake
     a.gscale = d_loss; a.d_emb = d_emb; a.dwb = d_weight_bias;
     GE2E_LAUNCH(h, loss_bwd_centroid_kernel, dim3(speakers, a.Y), dim3(256), 0, st, a);
     GE2E_LAUNCH(h, loss_bwd_row_kernel, dim3(a.N), dim3(256), 0, st, a);
+    if (d_weight_bias) GE2E_LAUNCH(h, loss_wb_reduce_kernel, dim3(1), dim3(256), 0, st, a);
     return 0;
 }
 

@@ -138,6 +138,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
     atomicAdd(p.dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
 }
 
+// gradient buffer <- 0 in ONE launch (hipMemsetAsync splits a buffer whose size is not a multiple of 16 bytes into two fill kernels, each a
+// dependent launch at the head of the backward)
+__global__ void __launch_bounds__(256) zero_f32_kernel(float* p, size_t n) {
+    const size_t n4 = n >> 2;
+    for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) ((f32x4*)p)[q] = f32x4{0, 0, 0, 0};
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.0f;
+}
+
 // dgamma / dbeta of a LayerNorm alone (the row part of its backward rides in the chained FFN backward kernel, ffn.cuh): column sums over all
 // rows of dy xhat and dy.  Half a wave per row (16 bytes per lane), 4 row pairs in flight per wave, per-lane accumulators for 8 columns;
 // a few hundred blocks, so that the final atomics (every block adds into the same 512 floats) stay a few hundred thousand.  Runs on the
@@ -326,13 +334,12 @@ struct LossArgs {
     const float* gscale;         // device scalar dL/dloss (backward)
     float* d_emb;                // [N,256]
     float* dwb;                  // [2] dL/dw, dL/db of the criterion's own parameters (reference Modules.py:115-116), or null
+    float* rowwb;                // [2][N] per-row terms of the two (summed by loss_wb_reduce_kernel)
 };
 
-// (block 0 also zeroes the loss accumulator the row kernel adds into)
 __global__ void __launch_bounds__(256) loss_centroid_kernel(const LossArgs p) {
     __shared__ float red[4];
     const int s = blockIdx.x, c = threadIdx.x;
-    if (s == 0 && c == 0) p.loss[0] = 0.0f;
     float acc = 0.0f;
     for (int q = 0; q < p.P; ++q) acc += p.emb[((size_t)s * p.P + q) * 256 + c];
     acc /= (float)p.P;
@@ -341,8 +348,8 @@ __global__ void __launch_bounds__(256) loss_centroid_kernel(const LossArgs p) {
     if (c == 0) p.cn[s] = nn;
 }
 
-// one block per utterance: cosines against every centroid, softmax cross-entropy, G0 = (softmax - onehot) / N (= dL/dsim); the row's
-// loss / N is added to the scalar (960 float atomics on one word: their order moves the last bit of the printed loss, nothing else)
+// one block per utterance: cosines against every centroid, softmax cross-entropy, G0 = (softmax - onehot) / N (= dL/dsim).  (The mean over
+// the rows stays a launch of its own: 960 float atomics on ONE word serialise at ~12 ns each -- measured +11 us on this 13 us kernel.)
 __global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* sims = (float*)smem;             // [S]
@@ -369,9 +376,7 @@ __global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
         const float lse = mx + logf(sum);
         if (lane == 0) {
             bc[0] = lse; p.en[irow] = en;
-            const float rl = lse - sims[own];
-            p.rowloss[irow] = rl;
-            atomicAdd(p.loss, rl / (float)p.N);
+            p.rowloss[irow] = lse - sims[own];
         }
     }
     __syncthreads();
@@ -383,11 +388,18 @@ __global__ void __launch_bounds__(256) loss_row_kernel(const LossArgs p) {
     }
 }
 
+__global__ void __launch_bounds__(256) loss_reduce_kernel(const LossArgs p) {
+    __shared__ float red[4];
+    float acc = 0.0f;
+    for (int q = threadIdx.x; q < p.N; q += 256) acc += p.rowloss[q];
+    const float t = block256_sum(acc, red);
+    if (threadIdx.x == 0) p.loss[0] = t / (float)p.N;
+}
+
 // dC_y[s][c] = w ((sum_i G0[i][s] ehat_i[c]) / cn_s - (sum_i G0[i][s] cos[i][s]) c_s[c] / cn_s^2) over slice y of the utterances: the expression
 // is linear in the two sums, so the row kernel adds the Y slabs.  grid = (S, Y)
 __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p) {
     const int s = blockIdx.x, c = threadIdx.x;
-    if (p.dwb && s == 0 && blockIdx.y == 0 && c < 2) p.dwb[c] = 0.0f;      // the row kernel (next launch) adds into it
     const int per = (p.N + gridDim.y - 1) / gridDim.y, q0 = blockIdx.y * per, q1 = min(p.N, q0 + per);
     float a = 0.0f, gc = 0.0f;
 #pragma unroll 4
@@ -415,7 +427,17 @@ __global__ void __launch_bounds__(256) loss_bwd_row_kernel(const LossArgs p) {
     const float en = p.en[irow], gsc = p.gscale[0];
     const float v = p.w * (a / en - gc * p.emb[(size_t)irow * 256 + c] / (en * en)) + dc / (float)p.P;
     p.d_emb[(size_t)irow * 256 + c] = v * gsc;
-    if (p.dwb && c == 0) { atomicAdd(p.dwb, gc * gsc); atomicAdd(p.dwb + 1, -gs * gsc); }
+    if (p.dwb && c == 0) { p.rowwb[irow] = gc * gsc; p.rowwb[p.N + irow] = -gs * gsc; }
+}
+
+// dL/dw = sum_i rowwb[0][i], dL/db = sum_i rowwb[1][i] (launched only when the caller wants them)
+__global__ void __launch_bounds__(256) loss_wb_reduce_kernel(const LossArgs p) {
+    __shared__ float red[4];
+    float a = 0.0f, b = 0.0f;
+    for (int q = threadIdx.x; q < p.N; q += 256) { a += p.rowwb[q]; b += p.rowwb[p.N + q]; }
+    a = block256_sum(a, red);
+    b = block256_sum(b, red);
+    if (threadIdx.x == 0) { p.dwb[0] = a; p.dwb[1] = b; }
 }
 
 // ---------------------------------------------------------------------------------------------
