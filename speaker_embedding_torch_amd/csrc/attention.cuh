@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 // every 16x16 tile of P and dS is a pure function of its own scores.
 //   Phase A (wave owns 16 queries; K, V in LDS): delta -> LDS, dQ^T += K^T dS^T.
 //   Phase B (wave owns 16 keys;    Q, dO in LDS): dV^T += dO^T Pd, dK^T += Q^T dS.
-template <typename T, int KT, bool PAD = true, int SBE = 5>
+// ABL (development only, tools/attn_bwd_bench.hip): 1 no phase B, 2 no phase A, 4 no dropout work, 8 no exp
+template <typename T, int KT, bool PAD = true, int SBE = 5, int ABL = 0>
 __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
@@ -207,11 +208,11 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
         st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
         st_d[q] = 0.0f;          // padded queries: phase B multiplies (dP - delta) by P = 0, so delta must be finite
     }
-    const bool dropping = p.drop.thr != 0;
+    const bool dropping = (ABL & 4) ? false : p.drop.thr != 0;
     if (USE_MASK && dropping) for (int q = threadIdx.x; q < TP * MW; q += blockDim.x) st_m[q] = 0u;
     const float ck = p.scale * ExpK<T>::K;
     __syncthreads();
-    for (int qt = wave; qt * 16 < p.T; qt += nw) {
+    for (int qt = wave; qt * 16 < p.T && !(ABL & 2); qt += nw) {
         const int qrow = qt * 16 + i;
         const bool vq = !PAD || qrow < p.T;
         u32x4 qf[G::NKG], dof[G::NKG];
@@ -253,7 +254,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float pr = ExpK<T>::ex(sa[r] * ck - lse);
+                    float pr = (ABL & 8) ? sa[r] * ck - lse : ExpK<T>::ex(sa[r] * ck - lse);
                     if (PAD && (16 * t + 4 * g + r) >= p.T) pr = 0.0f;
                     ds[u][r] = pr * (dp[r] - delta) * p.scale;
                 }
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     attn::load_tile<T>(bufA, qbase, ldq, p.T, TP);
     attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
     __syncthreads();
-    for (int kt = wave; kt * 16 < p.T; kt += nw) {
+    for (int kt = wave; kt * 16 < p.T && !(ABL & 1); kt += nw) {
         const int krow = kt * 16 + i;
         const bool vk = !PAD || krow < p.T;
         u32x4 kf[G::NKG], vf[G::NKG];
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * t + 4 * g + r;
-                    float pr = ExpK<T>::ex(sa[r] * ck - l4[r]);
+                    float pr = (ABL & 8) ? sa[r] * ck - l4[r] : ExpK<T>::ex(sa[r] * ck - l4[r]);
                     if (PAD && !((q < p.T) && vk)) pr = 0.0f;
                     float dv = da[r];
                     pd[u][r] = pr;

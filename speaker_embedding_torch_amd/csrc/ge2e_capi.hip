@@ -478,7 +478,10 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             // 256 blocks 4.29 ms, 192 4.19, 160 4.16, 128 4.20, 96 4.26).  GE2E_WGRAD_KS_BLOCKS overrides.
             static const int blocks_cap = [] { const char* e = getenv("GE2E_WGRAD_KS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : WK_DEFAULT_BLOCKS; }();
             const int ntile = tn * tk;
-            int splits = std::min(std::min(WK_MAX_BLOCKS, blocks_cap), h->num_cus) / ntile;
+            // (measured alone -- GE2E_K_SERIAL / GE2E_NO_OVERLAP: nothing to share the chip with -- a launch takes every CU)
+            bool alone = !h->overlap;
+            { std::lock_guard<std::mutex> g(h->mu); alone = alone || (h->prof_mask & GE2E_K_SERIAL) != 0; }
+            int splits = std::min(alone ? WK_MAX_BLOCKS : std::min(WK_MAX_BLOCKS, blocks_cap), h->num_cus) / ntile;
             // whole XCD rounds: the kernel deals row slices to the 8 XCDs (wgrad_ks.cuh), so a multiple of 8 leaves no XCD a block short
             if (splits >= 8) splits = std::min((splits + 4) / 8 * 8, WK_MAX_BLOCKS / ntile / 8 * 8);
             splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
