@@ -38,7 +38,7 @@ struct ParamInfo { std::string name; int64_t numel, offset; };
 
 }  // namespace
 
-struct ProfRec { int klass; hipEvent_t start, stop; double work, bytes; };
+struct ProfRec { int klass; hipEvent_t start, stop; double work, bytes; int counts; };
 
 struct ge2e_handle_s {
     ge2e_config cfg;
@@ -202,7 +202,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         }
         for (int s = 0; s < L.nqkv; ++s) L.dQKV[s] = take(R * 3 * d * e);
         L.adelta = t > 32 * MAX_KT ? take(R * (size_t)c.heads * 4) : (size_t)-1;
-        L.wpart = e == 2 ? take((size_t)WK_MAX_BLOCKS * WK_TILE_FLOATS * 4) : (size_t)-1;
+        L.wpart = e == 2 ? take((size_t)WK_MAX_JOBS * WK_MAX_BLOCKS * WK_TILE_FLOATS * 4) : (size_t)-1;     // one slab per product of a layer
         const size_t nn = (size_t)n;
         L.c_dP2 = take(nn * d * e); L.c_dM2 = take(nn * d * e);
         L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
@@ -229,13 +229,13 @@ inline int site_ff(int l) { return 4 + 4 * l; }
 // brackets one launch with events on its stream when its class is being profiled
 struct ProfScope {
     ge2e_handle h; hipStream_t st; bool on = false; ProfRec rec{};
-    ProfScope(ge2e_handle h_, hipStream_t st_, int klass, double work, double bytes = 0.0) : h(h_), st(st_) {
+    ProfScope(ge2e_handle h_, hipStream_t st_, int klass, double work, double bytes = 0.0, bool counts = true) : h(h_), st(st_) {
         if (!(h->prof_mask & klass)) return;
         auto get = [&]() { hipEvent_t e = nullptr;
             if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else if (hipEventCreate(&e) != hipSuccess) e = nullptr;
             return e; };
         std::lock_guard<std::mutex> g(h->mu);
-        rec.klass = klass; rec.work = work; rec.bytes = bytes; rec.start = get(); rec.stop = get();
+        rec.klass = klass; rec.work = work; rec.bytes = bytes; rec.counts = counts ? 1 : 0; rec.start = get(); rec.stop = get();
         on = rec.start && rec.stop;
         if (on) hipEventRecord(rec.start, st);
     }
@@ -461,8 +461,23 @@ inline bool ffn_chain_bwd_on() { static const bool off = getenv("GE2E_NO_FFN_CHA
 inline bool wgrad_ks_on() { static const bool off = getenv("GE2E_NO_WGRAD_KS") != nullptr; return !off; }
 template <typename T, int XLOAD> int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a);
 
+// reduce passes of the split-K products launched since the last flush (one slab each): flushed as ONE launch at the end of a layer
+struct WkPending {
+    WkReduceArgs args{};
+    int blocks = 0;
+    float* slab(float* base) const { return base + (size_t)args.njobs * WK_MAX_BLOCKS * WK_TILE_FLOATS; }
+};
+inline bool wk_batch_on() { static const bool off = getenv("GE2E_NO_REDUCE_BATCH") != nullptr; return !off; }
+int flush_wk_reduce(ge2e_handle h, hipStream_t st, WkPending& pend) {
+    if (pend.args.njobs == 0) return 0;
+    ProfScope ps(h, st, GE2E_K_WGRAD, 0.0, 0.0, /*counts=*/false);        // class time, not a launch of the class
+    GE2E_LAUNCH(h, wgrad_ks_reduce_multi_kernel, dim3(pend.blocks), dim3(512), 0, st, pend.args);
+    pend = WkPending{};
+    return 0;
+}
+
 template <typename T, int XLOAD>
-int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullptr) {
+int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullptr, WkPending* pend = nullptr) {
     if constexpr (sizeof(T) == 2) {
         const int tn = a.N / 256, tk = a.K / 256;
         if (part && wgrad_ks_on() && a.N % 256 == 0 && a.K % 256 == 0 && tn * tk >= 1 && tn * tk <= 16 && a.R >= 256 &&
@@ -487,6 +502,8 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
             const int sps = (stages + splits - 1) / splits;
             splits = (stages + sps - 1) / sps;
+            const bool batch = pend && wk_batch_on() && pend->args.njobs < WK_MAX_JOBS;
+            if (batch) part = pend->slab(part);
             WgradKsArgs k{};
             k.Y = a.Y; k.ldy = a.ldy; k.X = a.X; k.ldx = a.ldx; k.part = part; k.db = a.db; k.R32 = R32; k.rows_per_split = sps * 32;
             k.tiles_n = tn; k.tiles_k = tk; k.splits = splits;
@@ -506,6 +523,11 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
                 GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
                 // split groups: ~256 reduce blocks whatever the tile count (a single-tile product used to sum its 160 partials in 64 blocks)
                 const int sgroups = std::max(1, std::min(splits, 256 / (ntile * 32)));
+                if (batch) {
+                    WkReduceJob& j = pend->args.job[pend->args.njobs++];
+                    j.part = part; j.dW = a.dW; j.ldw = a.ldw; j.splits = splits; j.tiles_n = tn; j.tiles_k = tk; j.block0 = pend->blocks; j.sgroups = sgroups;
+                    pend->blocks += ntile * 32 * sgroups;
+                } else
                 GE2E_LAUNCH(h, wgrad_ks_reduce_kernel, dim3(ntile * 32, sgroups), dim3(512), 0, st, (const float*)part, a.dW, a.ldw, splits, tn, tk);
                 }
             }
@@ -900,6 +922,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     GE2E_LAUNCH(h, zero_f32_kernel, dim3(512), dim3(256), 0, st, grads, (size_t)h->total);
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
+    WkPending pend;                                       // this layer's reduce passes, flushed as one launch behind its last product
     // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
     hipEvent_t g_set1[2] = {nullptr, nullptr}, g_set2[2] = {nullptr, nullptr}, g_dF[2] = {nullptr, nullptr}, g_dQKV[3] = {nullptr, nullptr, nullptr};
     hipEvent_t g_dH[3] = {nullptr, nullptr, nullptr};    // last weight-gradient-stream reader of dHx[i] (the norm2 column sums)
@@ -1008,14 +1031,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_set1[bs] = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
             a.R = Rl; a.N = c.ffn; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_dF[bs] = sc.mark();
         }
         if (!chain_bwd) {   // dH1 = dPre2 + dF W1
@@ -1055,7 +1078,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
             a.R = Rl; a.N = d; a.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_set2[bs] = sc.mark();
         }
         sc.wait(g_dQKV[bq]);
@@ -1071,7 +1094,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs w{};
             w.Y = b_dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
             w.R = R; w.N = 3 * d; w.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart)));
+            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart, &pend)));
+            CK(flush_wk_reduce(h, wst, pend));
             g_dQKV[bq] = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
             g.A = b_dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = b_dHin; g.ldc = d;
@@ -1105,6 +1129,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wq)));
+            CK(flush_wk_reduce(h, wst, pend));
             CK(colsum_below(true));
         }
         if (cb && !forked_after_dh) sc.fork();     // the bucket is final behind the side stream (ge2e_bucket_stream): it now also follows this layer's main-stream kernels
@@ -1447,18 +1472,19 @@ int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_
         h->prof.swap(rest);
     }
     double ms = 0.0, work = 0.0, bytes = 0.0;
+    int64_t nlaunch = 0;
     for (auto& r : mine) {
         hipError_t e = hipEventSynchronize(r.stop);
         float t = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, r.start, r.stop);
         if (e != hipSuccess) return fail_hip(h, e, "profile event");
-        ms += t; work += r.work; bytes += r.bytes;
+        ms += t; work += r.work; bytes += r.bytes; nlaunch += r.counts;
     }
     {
         std::lock_guard<std::mutex> g(h->mu);
         for (auto& r : mine) { h->ev_pool.push_back(r.start); h->ev_pool.push_back(r.stop); }
     }
-    *total_ms = ms; *total_work = work; *total_bytes = bytes; *launches = (int64_t)mine.size();
+    *total_ms = ms; *total_work = work; *total_bytes = bytes; *launches = nlaunch;
     return 0;
 }
 

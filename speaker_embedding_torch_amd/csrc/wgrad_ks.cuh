@@ -224,16 +224,21 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
 // bytes per wave instruction (the full-rate atomic shape; dW is at most 1 MB and lives in the caches, so these few MB of
 // atomics cost nothing next to the partial reads).  grid = (tiles * 32, split groups).
 // (Round 2: one thread per fragment element summed ALL splits serially and read-modify-wrote dW in 64-byte pieces: 20-60 us.)
-__global__ void __launch_bounds__(512) wgrad_ks_reduce_kernel(const float* part, float* dW, int ldw, int splits, int tiles_n, int tiles_k) {
-    __shared__ float tr[16][132];
+// (Round 3, second half: the reduce passes of ONE layer's products run as one launch -- up to WK_MAX_JOBS jobs, each with its own partial
+// slab --, deferred to the layer's last product: a reduce pass is a dependent launch of ~9 us that waits for whole CUs next to kernels
+// that fill every register of theirs; in the step the 11 passes measured 31 us on average, 200 us at worst, on the stream that ends last.)
+constexpr int WK_MAX_JOBS = 4;
+struct WkReduceJob { const float* part; float* dW; int ldw, splits, tiles_n, tiles_k, block0, sgroups; };
+struct WkReduceArgs { WkReduceJob job[WK_MAX_JOBS]; int njobs; };
+
+__device__ __forceinline__ void wk_reduce_body(const float* part, float* dW, int ldw, int splits, int tiles_n, int tiles_k, int bx, int by, int sg, float (*tr)[132]) {
     const int ntile = tiles_n * tiles_k;
-    const int tile = blockIdx.x >> 5, grp = blockIdx.x & 31;          // grp = wave * 4 + mt
+    const int tile = bx >> 5, grp = bx & 31;          // grp = wave * 4 + mt
     const int t = threadIdx.x, lane = t & 63, nt = t >> 6;
     const f32x4* src = (const f32x4*)(part + (size_t)tile * WK_TILE_FLOATS) + grp * 512 + t;
     const size_t stride = (size_t)ntile * (WK_TILE_FLOATS / 4);
     f32x4 s0 = f32x4{0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
-    int sp = blockIdx.y;
-    const int sg = gridDim.y;
+    int sp = by;
     for (; sp + 3 * sg < splits; sp += 4 * sg) {
         const f32x4 a = __builtin_nontemporal_load(src + (size_t)sp * stride), b = __builtin_nontemporal_load(src + (size_t)(sp + sg) * stride);
         const f32x4 c = __builtin_nontemporal_load(src + (size_t)(sp + 2 * sg) * stride), d = __builtin_nontemporal_load(src + (size_t)(sp + 3 * sg) * stride);
@@ -252,6 +257,20 @@ __global__ void __launch_bounds__(512) wgrad_ks_reduce_kernel(const float* part,
         const int e = q * 512 + t, row = e >> 7, col = e & 127;
         atomicAdd(dW + (size_t)(n0 + row) * ldw + k0 + col, tr[row][col]);
     }
+}
+__global__ void __launch_bounds__(512) wgrad_ks_reduce_kernel(const float* part, float* dW, int ldw, int splits, int tiles_n, int tiles_k) {
+    __shared__ float tr[16][132];
+    wk_reduce_body(part, dW, ldw, splits, tiles_n, tiles_k, blockIdx.x, blockIdx.y, gridDim.y, tr);
+}
+// grid = sum over the jobs of tiles * 32 * sgroups blocks; job j owns blocks [block0_j, block0_{j+1})
+__global__ void __launch_bounds__(512) wgrad_ks_reduce_multi_kernel(const WkReduceArgs a) {
+    __shared__ float tr[16][132];
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < WK_MAX_JOBS; ++q) if (q < a.njobs && (int)blockIdx.x >= a.job[q].block0) j = q;
+    const WkReduceJob& w = a.job[j];
+    const int local = blockIdx.x - w.block0, per = w.tiles_n * w.tiles_k * 32;
+    wk_reduce_body(w.part, w.dW, w.ldw, w.splits, w.tiles_n, w.tiles_k, local % per, local / per, w.sgroups, tr);
 }
 
 }  // namespace ge2e
