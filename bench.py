@@ -14,7 +14,8 @@ rank: forward -> GE2E loss -> backward (bucketed RCCL gradient mean overlapped w
 on, bf16 storage / fp32 accumulate.  Inputs are generated on the device before the timed region.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     live hipEvent timing of the dominant kernel class (projection GEMMs) inside the timed region
+  "roofline":     live hipEvent timing of the dominant kernel class (--roofline-kernel, default the weight gradients: the top
+                  rocprofv3 row) inside the timed region, and the same launches again with the backward's two streams serialised
   "cpu_baseline": a PyTorch-CPU restatement of the same Train_Step (oracle/torch_restatement.py: what the reference's
                   Device '-1' path executes) timed on this box's host cores on the FULL batch, 1 warm-up + 3 steps,
                   best-of (N = 1, rank 0 only).

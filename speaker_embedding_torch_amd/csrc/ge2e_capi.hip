@@ -1,6 +1,8 @@
 // libge2e_hip.so: C-ABI entry points (include/ge2e_hip.h) and the launch sequence of the GE2E hot path.
-// One encoder forward = weight prep + prenet GEMM + per layer {in_proj GEMM, fused attention,
-// out_proj GEMM+LN, FFN1 GEMM, FFN2 GEMM+LN} + tail.  Everything is enqueued on the caller's stream.
+// One encoder forward = weight prep + mel pack + prenet GEMM + per full layer {in_proj GEMM, fused attention, out_proj GEMM + LN,
+// chained FFN (16-bit modes) | FFN1 GEMM, FFN2 GEMM + LN} + the last layer on one row per utterance (single-query attention without
+// K / V, attn_last.cuh) + tail; the backward mirrors it (chained FFN backward, norm1 backward + dO, attention backward, dgrad GEMM per
+// full layer) with the weight gradients on an internal side stream.  Everything else is enqueued on the caller's stream.
 #include "../../include/ge2e_hip.h"
 
 #include <hip/hip_ext.h>
@@ -116,7 +118,8 @@ struct Layout {
     // qk = Wk_h^T q0_h [n, 4, 256], the probabilities [n, 4, T], ctx = sum_t pd_t x_t [n, 4, 256], sum_t pd_t [n, 4] (all fp32) and, in
     // backward, dqk [n, 4, 256]
     size_t lq0 = 0, lqk = 0, lprob = 0, lctx = 0, lsp = 0, ldqk = 0;
-    size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): 256 x 256 KB
+    size_t wpart = 0;            // split-K partial tiles of the 256 x 256 weight-gradient kernel (16-bit modes): WK_MAX_JOBS slabs (one per product of a layer)
+    size_t wslab = 0;            // floats per slab: as many 256 x 256 tiles as a launch at this row count can have blocks
     size_t xhat_f = 0, rstd_f = 0, zm = 0, nrm = 0, emb_keep = 0, d_raw = 0;
     size_t dHb = 0, dO = 0;
     // dL/d(output of layer l) lives in dHx[(l + 1) % nH] (l = -1: the prenet output).  The weight-gradient stream reads it too (the
@@ -134,7 +137,7 @@ struct Layout {
     size_t dP2[2] = {0, 0}, dM2[2] = {0, 0}, c_dP2 = 0, c_dM2 = 0;
     // last layer: only frame 0 of its output is consumed, so everything after its K/V projection lives on
     // COMPACT rows (one per utterance): o/h1/f/h2 of that layer and this backward scratch
-    size_t c_dH = 0, c_dHb = 0, c_dP = 0, c_dM = 0, c_dF = 0, c_dO = 0, c_dQ0 = 0, c_tmp = 0;
+    size_t c_dH = 0, c_dHb = 0, c_dP = 0, c_dM = 0, c_dF = 0, c_dO = 0, c_dQ0 = 0;
     size_t total = 0;
 };
 
@@ -202,11 +205,15 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         }
         for (int s = 0; s < L.nqkv; ++s) L.dQKV[s] = take(R * 3 * d * e);
         L.adelta = t > 32 * MAX_KT ? take(R * (size_t)c.heads * 4) : (size_t)-1;
-        L.wpart = e == 2 ? take((size_t)WK_MAX_JOBS * WK_MAX_BLOCKS * WK_TILE_FLOATS * 4) : (size_t)-1;     // one slab per product of a layer
+        {   // a launch has tiles x slices blocks, slices <= rows / 256 (8 stages of 32 rows per block at least) and <= WK_MAX_BLOCKS / tiles
+            const size_t tiles = std::max<size_t>(3, std::min<size_t>(16, f / 256));
+            L.wslab = std::min<size_t>(WK_MAX_BLOCKS, tiles * std::max<size_t>(1, R / 256)) * WK_TILE_FLOATS;
+        }
+        L.wpart = e == 2 ? take((size_t)WK_MAX_JOBS * L.wslab * 4) : (size_t)-1;
         const size_t nn = (size_t)n;
         L.c_dP2 = take(nn * d * e); L.c_dM2 = take(nn * d * e);
         L.c_dH = take(nn * d * e); L.c_dHb = take(nn * d * e); L.c_dP = take(nn * d * e); L.c_dM = take(nn * d * e);
-        L.c_dF = take(nn * f * e); L.c_dO = take(nn * d * e); L.c_dQ0 = take(nn * d * e); L.c_tmp = take(nn * d * e);
+        L.c_dF = take(nn * f * e); L.c_dO = take(nn * d * e); L.c_dQ0 = take(nn * d * e);
     }
     L.total = off;
     return L;
@@ -300,8 +307,7 @@ int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     const double kk = a.K;
     // algorithmic HBM bytes of one launch: activations in (fp32 mel for the prenet) + weights + tile out (+ tile in)
     const double abytes = (double)a.M * kk * (double)sizeof(T) + (double)a.N * kk * sizeof(T) +
-                          (double)a.M * a.N * sizeof(T) * (reads_r ? 2.0 : 1.0) +
-                          (EPI == EPI_ADD_ROW0 ? (double)(a.M / std::max(1, a.T)) * a.N * sizeof(T) : 0.0);
+                          (double)a.M * a.N * sizeof(T) * (reads_r ? 2.0 : 1.0);
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * kk, abytes);
     GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), smem, st, a);
     return 0;
@@ -465,14 +471,17 @@ template <typename T, int XLOAD> int launch_wgrad_tiled(ge2e_handle h, hipStream
 struct WkPending {
     WkReduceArgs args{};
     int blocks = 0;
-    float* slab(float* base) const { return base + (size_t)args.njobs * WK_MAX_BLOCKS * WK_TILE_FLOATS; }
+    size_t slab_floats = 0;              // Layout::wslab
+    float* slab(float* base) const { return base + (size_t)args.njobs * slab_floats; }
 };
 inline bool wk_batch_on() { static const bool off = getenv("GE2E_NO_REDUCE_BATCH") != nullptr; return !off; }
 int flush_wk_reduce(ge2e_handle h, hipStream_t st, WkPending& pend) {
     if (pend.args.njobs == 0) return 0;
     ProfScope ps(h, st, GE2E_K_WGRAD, 0.0, 0.0, /*counts=*/false);        // class time, not a launch of the class
     GE2E_LAUNCH(h, wgrad_ks_reduce_multi_kernel, dim3(pend.blocks), dim3(512), 0, st, pend.args);
+    const size_t keep = pend.slab_floats;
     pend = WkPending{};
+    pend.slab_floats = keep;
     return 0;
 }
 
@@ -502,6 +511,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
             const int sps = (stages + splits - 1) / splits;
             splits = (stages + sps - 1) / sps;
+            if (pend && (size_t)ntile * splits * WK_TILE_FLOATS > pend->slab_floats) return fail(h, GE2E_EWORKSPACE, "wgrad_ks: partial slab too small for this launch");
             const bool batch = pend && wk_batch_on() && pend->args.njobs < WK_MAX_JOBS;
             if (batch) part = pend->slab(part);
             WgradKsArgs k{};
@@ -923,6 +933,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
     WkPending pend;                                       // this layer's reduce passes, flushed as one launch behind its last product
+    pend.slab_floats = L.wslab;
     // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
     hipEvent_t g_set1[2] = {nullptr, nullptr}, g_set2[2] = {nullptr, nullptr}, g_dF[2] = {nullptr, nullptr}, g_dQKV[3] = {nullptr, nullptr, nullptr};
     hipEvent_t g_dH[3] = {nullptr, nullptr, nullptr};    // last weight-gradient-stream reader of dHx[i] (the norm2 column sums)

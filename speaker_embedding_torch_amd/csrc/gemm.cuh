@@ -11,7 +11,7 @@
 
 namespace ge2e {
 
-enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_ADD_ROW0,
+enum { EPI_NONE = 0, EPI_BIAS, EPI_BIAS_RELU_DROP, EPI_LN, EPI_MASK, EPI_ADD, EPI_PRENET, EPI_PRENET_BWD, EPI_RESERVED8 /* was EPI_ADD_ROW0: the last layer's K/V dgrad, gone with attn_last.cuh */,
        EPI_MASKBITS /* EPI_MASK with the mask as one BIT per element: R = [M][ldr bytes], bits in the byte order of ffn.cuh ffn_mask_byte (gemm_ws only) */ };
 enum { ALOAD_ROW = 0 };     // operand rows are read row-major (the mel batch is packed to rows first: mel_pack_kernel)
 
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
     // All global traffic of the epilogue is 16 bytes per lane along rows: the residual / mask / addend tile
     // comes in through LDS, each lane transforms its 4-column groups in place, and the finished tile goes out
     // with full-line stores (the MFMA layout itself would give 32-byte segments per row).
-    constexpr bool NEEDS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD || EPI == EPI_ADD_ROW0);
+    constexpr bool NEEDS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
     const uint32_t drm = p.drow_mul > 0 ? (uint32_t)p.drow_mul : 1u;
     if constexpr (EPI == EPI_LN) {
         // Row-complete tile (BN == N == 256): park the raw fp32 accumulators in LDS, then every wave finishes whole
@@ -194,10 +194,6 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
             for (int q = 0; q < 8 && q0 + q < NCC; ++q) {
                 const int id = tid + 256 * (q0 + q), row = id / CPRC, c = id % CPRC, gr = m0 + row;
-                if constexpr (EPI == EPI_ADD_ROW0) {     // addend exists for frame-0 rows only: R is [M / T, N] compact
-                    const int un = gr / p.T;
-                    rr[q] = (gr < p.M && gr == un * p.T) ? *(const u32x4*)(Rg + ((size_t)un * p.ldr + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
-                } else
                 rr[q] = gr < p.M ? *(const u32x4*)(Rg + ((size_t)gr * p.ldr + n0) * sizeof(T) + c * 16) : u32x4{0, 0, 0, 0};
             }
 #pragma unroll
@@ -255,7 +251,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = m4[r] > 0.0f ? v[r] * p.mask_scale : 0.0f;
                 }
-                if constexpr (EPI == EPI_ADD || EPI == EPI_ADD_ROW0) v += load4(crow + lcolb + nt * 16);
+                if constexpr (EPI == EPI_ADD) v += load4(crow + lcolb + nt * 16);
                 store4(crow + lcolb + nt * 16, v[0], v[1], v[2], v[3]);
             }
         }
