@@ -17,8 +17,8 @@ CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
     # what bench.py's wgrad class brackets: one scope per product = wgrad_ks_kernel + its reduce pass, or one wgrad_kernel launch
     # (NOT tail_wgrad_kernel, which "wgrad_kernel" in n would also match).  Per LAUNCH of the class = per product: the reduce
     # pass's bytes are added to its product's, so the class count is the number of wgrad_ks + wgrad_kernel dispatches.
-    "wgrad": lambda n: ("wgrad_ks_kernel" in n or "wgrad_ks_reduce_kernel" in n or "ge2e::wgrad_kernel" in n or "ge2e12wgrad_kernel" in n),
-    "wgrad_reduce": lambda n: "wgrad_ks_reduce_kernel" in n,
+    "wgrad": lambda n: ("wgrad_ks_kernel" in n or "wgrad_ks_reduce" in n or "ge2e::wgrad_kernel" in n or "ge2e12wgrad_kernel" in n),
+    "wgrad_reduce": lambda n: "wgrad_ks_reduce" in n,
     "ffn": lambda n: "ffn_chain_kernel" in n,
     "attn_fwd": lambda n: "attn_fwd_kernel" in n,
     "attn_bwd": lambda n: "attn_bwd_kernel" in n,
@@ -71,7 +71,7 @@ def main():
         for r in rows:
             if pred(r[0]):
                 tot += (r[3] + r[5]) * r[1]
-                if not (name == "wgrad" and "wgrad_ks_reduce_kernel" in r[0]):     # a reduce pass belongs to its product's launch
+                if not (name == "wgrad" and "wgrad_ks_reduce" in r[0]):     # a reduce pass belongs to its products' launches
                     n += r[1]
         if n:
             classes[name] = round(tot / n)
