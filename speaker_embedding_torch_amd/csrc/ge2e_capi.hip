@@ -594,7 +594,12 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
         auto kern = attn_fwd_kernel<T, KT, PAD>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
-        const size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 ? (size_t)TP * (TP / 32) * 4 : 0);
+        size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 ? (size_t)TP * (TP / 32) * 4 : 0);
+        // Two blocks of >= 5 waves per CU are enough for this kernel (960 x 160 alone: 310 us at 2 blocks per CU, 318-329 at 3, 415 at 1), and the
+        // third block only takes registers and LDS from whatever the weight-gradient stream has in flight: a launch that would fit three asks
+        // for a little more LDS than a third of the CU's (step 3.785 -> 3.742 ms).  GE2E_ATTN_BWD_3PERCU=1 restores the natural occupancy.
+        static const bool three = getenv("GE2E_ATTN_BWD_3PERCU") != nullptr;
+        if (!three && nw >= 5 && 3 * smem <= (size_t)160 * 1024) smem = (size_t)160 * 1024 / 3 + 1024;
         // scheduling-barrier spacing must not exceed the tile-group count of the loops it paces (KT groups in bf16): with the
         // default 5 the short-T instances (KT <= 4) never hit a barrier, hipcc hoisted every fragment load, 247-256 VGPRs + spills
         constexpr int SBE = KT >= 5 ? 5 : (KT >= 2 ? 2 : 1);

@@ -18,9 +18,9 @@ __global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         p[i] = (bf16_t)(((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f);
 }
-template <int ABL> void run(const AttnArgs& a, int n, const char* tag) {
+template <int ABL> void run(const AttnArgs& a, int n, const char* tag, size_t extra_lds = 0) {
     using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    const size_t sb = 2 * (size_t)TP * G::LD + 2 * TP * 4 + TP * (TP / 32) * 4;
+    const size_t sb = 2 * (size_t)TP * G::LD + 2 * TP * 4 + TP * (TP / 32) * 4 + extra_lds;
     auto kb = attn_bwd_kernel<T, KT, false, 5, ABL>;
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
     printf("%-44s abl %2d  %7.1f us\n", tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(320), sb, 0, a); }));
@@ -33,6 +33,8 @@ int main() {
     AttnArgs a{}; a.qkv = qkv; a.o = o; a.dout = dout; a.dqkv = dqkv; a.T = T_; a.H = 4; a.D = D; a.scale = 0.125f; a.lse = lse;
     a.drop = Drop{12345u, 6553u, 1.1111f};
     for (int rep = 0; rep < 2; ++rep) run<0>(a, n, "full");
+    run<0>(a, n, "full, 2 blocks per CU (LDS padded to 70 KB)", 25 * 1024);
+    run<0>(a, n, "full, 1 block per CU (LDS padded to 100 KB)", 55 * 1024);
     run<1>(a, n, "phase A only");
     run<2>(a, n, "phase B only (+ tile loads of A)");
     run<3>(a, n, "tile loads + barriers only");
