@@ -98,7 +98,8 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
 }
 }  // namespace attn
 
-template <typename T, int KT, bool PAD = true, int SBE = 1>
+// ABL (development only, tools/attn_bwd_bench.hip): 1 no compute (tile loads + barrier only), 2 no dropout, 4 no exp, 8 no P.V
+template <typename T, int KT, bool PAD = true, int SBE = 1, int ABL = 0>
 __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     attn::load_tile<T>(Vs, base + (size_t)2 * p.D * sizeof(T), ldq, p.T, TP);
     __syncthreads();
 
-    for (int qt = wave; qt * 16 < p.T; qt += nw) {       // wave-uniform loop: EXEC stays full
+    for (int qt = wave; qt * 16 < p.T && !(ABL & 1); qt += nw) {       // wave-uniform loop: EXEC stays full
         const int qrow = qt * 16 + i;
         const bool vq = !PAD || qrow < p.T;                // PAD == false: T is a multiple of 32, no masking anywhere
         u32x4 qf[G::NKG];
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const float e = ExpK<T>::ex(s[t][r] * ck - mk); s[t][r] = e; sum += e; }
+            for (int r = 0; r < 4; ++r) { const float e = (ABL & 4) ? s[t][r] * ck - mk : ExpK<T>::ex(s[t][r] * ck - mk); s[t][r] = e; sum += e; }
         const float tot = cross4_sum(sum);
         const float inv = 1.0f / tot;
         if (p.lse && g == 0 && vq) p.lse[((size_t)n * p.T + qrow) * p.H + h] = mx * p.scale + logf(tot);
@@ -146,14 +147,14 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
         for (int t = 0; t < NT16; ++t) { const int sb_i = t;
             s[t] *= inv;
-            drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t]);
+            if (!(ABL & 2)) drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t]);
         }
 
         f32x4 oacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int gi = 0; gi < NG; ++gi) { const int sb_i = gi;
+        for (int gi = 0; gi < ((ABL & 8) ? 1 : NG); ++gi) { const int sb_i = gi;
             const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // O^T[d = 16dt+4g+r][query] += V^T[d][keys] * P^T[keys][query]

@@ -18,6 +18,7 @@
 
 #include "attention.cuh"
 #include "attn_last.cuh"
+#include "prenet_bwd.cuh"
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
@@ -109,6 +110,7 @@ struct Layout {
     size_t w_l1[MAX_LAYERS], w_l1T[MAX_LAYERS], w_l2[MAX_LAYERS], w_l2T[MAX_LAYERS];
     size_t wqT = 0, pe_t = 0, h0 = 0;
     size_t xt = 0;               // packed mel: [R][KP] of T (row-major copy of the channels-first fp32 input)
+    size_t pbits = 0;            // [R][32] sign bits of the prenet's pre-activation (train: written by its forward epilogue, read by prenet_bwd_kernel)
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
     size_t fbits[MAX_LAYERS];    // [R, ffn / 8] bytes: "stored FFN hidden > 0", one bit per element (train, 16-bit modes, full layers;
@@ -161,6 +163,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
     L.pe_t = take((size_t)t * d * 4);
     L.xt = take(R * (size_t)L.KP * e);
     L.h0 = take(R * d * e);
+    L.pbits = train ? take(R * (d / 8)) : (size_t)-1;
     const int last = c.layers - 1;
     if (train) {
         for (int l = 0; l < c.layers; ++l) {
@@ -817,6 +820,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(train, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.alpha = P[P_ALPHA]; a.T = t; a.mel = c.mel_dim;
+        a.relu_bits = train ? ws + L.pbits : nullptr;
         CK((gemm128<T, EPI_PRENET>(h, st, a)));
     }
     for (int l = 0; l < c.layers; ++l) {
@@ -1152,21 +1156,41 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         if (tail_bucket_pending) { bucket(p_fn_w(c), p_proj_b(c)); tail_bucket_pending = false; }
         bucket(lp(l, 0), lp(l, L_COUNT - 1));
     }
-    {   // through PE dropout, alpha * pe, ReLU: recompute the prenet pre-activation, mask dH0 in place
-        GemmArgs a{};
+    {   // through the PE dropout, alpha * pe and the ReLU, and the prenet's weight / bias gradients, in one launch (prenet_bwd.cuh): the masked
+        // gradient of the pre-activation is formed on the way into the weight-gradient kernel's LDS tiles and never stored.  It stays on the
+        // MAIN stream: the side stream's own last job (layer 0's in_proj gradient) ends later than this does.
+        static const bool unfused = getenv("GE2E_NO_PRENET_FUSE") != nullptr;
         unsigned char* const dH0 = ws + L.dH_of(-1);
+        if (!unfused) {
+            constexpr int RS = 2 * Prec<T>::KG;
+            constexpr int LD = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+            PrenetBwdArgs a{};
+            a.dH0 = dH0; a.X = ws + L.xt; a.ldx = L.KP; a.bits = ws + L.pbits; a.pe_t = (const float*)(ws + L.pe_t);
+            a.dW = G(P_PRENET_W); a.ldw = c.mel_dim; a.db = G(P_PRENET_B); a.dalpha = G(P_ALPHA);
+            a.R = R; a.K = c.mel_dim; a.T = t; a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
+            int splits = 256;
+            const int max_splits = (R + 4 * RS - 1) / (4 * RS);
+            splits = std::max(1, std::min(splits, max_splits));
+            int rps = (R + splits - 1) / splits;
+            rps = (rps + RS - 1) / RS * RS;
+            splits = (R + rps - 1) / rps;
+            a.rows_per_split = rps;
+            const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
+            ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R * d * c.mel_dim, (double)R * (d + L.KP) * sizeof(T) + (double)R * d / 8 + 4.0 * d * c.mel_dim);
+            auto kern = prenet_bwd_kernel<T>;
+            GE2E_LAUNCH(h, kern, dim3(2 * splits), dim3(256), smem, st, a);
+        } else {
+        GemmArgs a{};
         a.A = ws + L.xt; a.lda = L.KP; a.W = ws + L.w_prenet; a.ldw = L.KP; a.C = dH0; a.ldc = d; a.R = dH0; a.ldr = d;
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
         CK((gemm128<T, EPI_PRENET_BWD>(h, st, a)));
-        // the last weight gradient stays on the MAIN stream: on the side stream it would start a fence later and the join would
-        // wait for it, while the side stream's own last job (layer 0's in_proj gradient) ends about when this GEMM does
-        // (measured 4.05 vs 4.07 ms per step)
         WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
         w.Y = dH0; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
         CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));                 // (no split-K scratch here: wpart belongs to the side stream)
+        }
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
     }
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again

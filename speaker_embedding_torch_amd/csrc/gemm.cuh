@@ -30,6 +30,7 @@ struct GemmArgs {
     const float* alpha;          // positional_encoding.alpha (device scalar)
     float* dalpha;               // EPI_PRENET_BWD: scalar accumulator
     int T, mel;                  // frames per utterance (prenet epilogues: row -> frame), real mel dim
+    unsigned char* relu_bits;    // EPI_PRENET (train): [M][N / 8] bytes, bit c & 7 of byte c >> 3 = "pre-activation of column c > 0" (prenet_bwd.cuh reads it)
 };
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2>
@@ -214,6 +215,7 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
         {
             int t = 0;
             if constexpr (EPI == EPI_PRENET || EPI == EPI_PRENET_BWD) t = row < p.M ? row % p.T : 0;
+            [[maybe_unused]] unsigned long long sbits = 0ull;     // EPI_PRENET: this lane's sign nibbles of the wave's WN columns of the row
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = colb + nt * 16;
@@ -230,6 +232,10 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
                 if constexpr (EPI == EPI_PRENET) {
                     const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)t * p.N + col);
                     const float al = *p.alpha;
+                    if (p.relu_bits) {
+                        const unsigned nib = (unsigned)(v[0] > 0.0f) | ((unsigned)(v[1] > 0.0f) << 1) | ((unsigned)(v[2] > 0.0f) << 2) | ((unsigned)(v[3] > 0.0f) << 3);
+                        sbits |= (unsigned long long)nib << (16 * nt + 4 * g);       // column lcolb + 16 nt + r - wn WN = 16 nt + 4 g + r
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) + al * pe4[r];
                     drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
@@ -253,6 +259,15 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
                 }
                 if constexpr (EPI == EPI_ADD) v += load4(crow + lcolb + nt * 16);
                 store4(crow + lcolb + nt * 16, v[0], v[1], v[2], v[3]);
+            }
+            if constexpr (EPI == EPI_PRENET) {
+                if (p.relu_bits) {      // (wave-uniform) the four lanes of a row hold disjoint nibbles: OR them, one store of WN / 8 bytes per row
+                    static_assert(WN == 64, "one 64-bit word per row and wave");
+                    unsigned lo = (unsigned)sbits, hi = (unsigned)(sbits >> 32);
+                    lo |= __shfl_xor(lo, 16, 64); lo |= __shfl_xor(lo, 32, 64);
+                    hi |= __shfl_xor(hi, 16, 64); hi |= __shfl_xor(hi, 32, 64);
+                    if (g == 0 && row < p.M) *(u32x2*)(p.relu_bits + (size_t)row * (p.N / 8) + (n0 + wn * WN) / 8) = u32x2{lo, hi};
+                }
             }
         }
     }

@@ -25,6 +25,13 @@ template <int ABL> void run(const AttnArgs& a, int n, const char* tag, size_t ex
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
     printf("%-44s abl %2d  %7.1f us\n", tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(320), sb, 0, a); }));
 }
+template <int ABL> void runf(const AttnArgs& a, int n, const char* tag, size_t extra_lds = 0) {
+    using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
+    const size_t sf = 2 * (size_t)TP * G::LD + extra_lds;
+    auto kf = attn_fwd_kernel<T, KT, false, 1, ABL>;
+    CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
+    printf("fwd %-40s abl %2d  %7.1f us\n", tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kf, dim3(n * 4), dim3(320), sf, 0, a); }));
+}
 int main() {
     const int n = 960, T_ = 160, D = 256; const size_t R = (size_t)n * T_;
     bf16_t *qkv, *o, *dout, *dqkv; float* lse;
@@ -42,6 +49,14 @@ int main() {
     run<8>(a, n, "no exp");
     run<12>(a, n, "no dropout, no exp");
     run<5>(a, n, "phase A only, no dropout");
+    for (int rep = 0; rep < 2; ++rep) runf<0>(a, n, "full");
+    runf<0>(a, n, "full, 3 blocks per CU", 14 * 1024);
+    runf<0>(a, n, "full, 2 blocks per CU", 30 * 1024);
+    runf<1>(a, n, "tile loads + barrier only");
+    runf<2>(a, n, "no dropout");
+    runf<4>(a, n, "no exp");
+    runf<8>(a, n, "no P.V (one group)");
+    runf<6>(a, n, "no dropout, no exp");
     run<6>(a, n, "phase B only, no dropout");
     return 0;
 }
