@@ -349,6 +349,32 @@ def test_loss_scaled_step_matches_torch_gradscaler_semantics():
     assert GradScaler(enabled=False).scale(torch.ones((), device="cuda")).item() == 1.0
 
 
+def test_loss_scaling_refuses_param_groups_and_reseeds_steps_after_load():
+    """One scale / growth-tracker update per step: several param_groups under a GradScaler are refused (the fused step ends with the
+    scaler update, once per call); and `load_state_dict` after scaled steps re-seeds the device-side step counter from the loaded 'step'."""
+    from speaker_embedding_torch_amd.Optim import FusedClipAdamW, GradScaler
+    torch.manual_seed(2)
+    a, b = torch.nn.Parameter(torch.randn(300, device="cuda")), torch.nn.Parameter(torch.randn(70, device="cuda"))
+    two = FusedClipAdamW([{"params": [a]}, {"params": [b], "lr": 1e-3}], lr=1e-2, max_norm=1.0)
+    a.grad, b.grad = torch.randn_like(a), torch.randn_like(b)
+    with pytest.raises(RuntimeError, match="one param_group"):
+        GradScaler(init_scale=8.0).step(two)
+    two.step()                                                            # without a scaler several groups are fine
+    one = FusedClipAdamW([a, b], lr=1e-2, max_norm=1.0)
+    sc = GradScaler(init_scale=8.0)
+    for _ in range(3):
+        a.grad, b.grad = torch.randn_like(a) * 8, torch.randn_like(b) * 8
+        sc.step(one)
+    sd = one.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    for st in sd["state"].values():
+        st["step"] = torch.tensor(10.0)
+    one.load_state_dict(sd)
+    a.grad, b.grad = torch.randn_like(a) * 8, torch.randn_like(b) * 8
+    sc.step(one)
+    assert sc.steps_taken() == 11                                         # continued from the loaded count, not from the device's 3
+
+
 @pytest.mark.timeout(300)
 def test_many_steps_enqueued_without_a_host_sync(tmp_path):
     """Regression for the round-1 stream deadlock (a fence event re-recorded while the side stream still had to wait on

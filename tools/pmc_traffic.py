@@ -17,7 +17,7 @@ CLASSES = {   # bench.py --roofline-kernel name -> predicate on the kernel name
     # what bench.py's wgrad class brackets: one scope per product = wgrad_ks_kernel + its reduce pass, or one wgrad_kernel launch
     # (NOT tail_wgrad_kernel, which "wgrad_kernel" in n would also match).  Per LAUNCH of the class = per product: the reduce
     # pass's bytes are added to its product's, so the class count is the number of wgrad_ks + wgrad_kernel dispatches.
-    "wgrad": lambda n: ("wgrad_ks_kernel" in n or "wgrad_ks_reduce" in n or "ge2e::wgrad_kernel" in n or "ge2e12wgrad_kernel" in n),
+    "wgrad": lambda n: ("wgrad_ks_kernel" in n or "wgrad_ks_reduce" in n or "ge2e::wgrad_kernel" in n or "ge2e12wgrad_kernel" in n or "prenet_bwd_kernel" in n),
     "wgrad_reduce": lambda n: "wgrad_ks_reduce" in n,
     "ffn": lambda n: "ffn_chain_kernel" in n,
     "attn_fwd": lambda n: "attn_fwd_kernel" in n,
