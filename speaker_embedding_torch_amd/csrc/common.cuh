@@ -72,16 +72,18 @@ template <> __device__ __forceinline__ float from_f32<float>(float v) { return v
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 template <> __device__ __forceinline__ f16_t from_f32<f16_t>(float v) { return (f16_t)v; }     // round to nearest even; overflow -> inf (the loss scaler's cue)
 
+// two floats -> one packed pair, ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32, round to nearest even as the scalar casts).
+// Written as two scalar casts + shift + or, the compiler emits two conversions, a shift and an or: four instructions per pair in every
+// epilogue that packs accumulators.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    unsigned short a = __builtin_bit_cast(unsigned short, (bf16_t)lo);
-    unsigned short b = __builtin_bit_cast(unsigned short, (bf16_t)hi);
-    return (unsigned)a | ((unsigned)b << 16);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
 }
 
 __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
-    unsigned short a = __builtin_bit_cast(unsigned short, (f16_t)lo);
-    unsigned short b = __builtin_bit_cast(unsigned short, (f16_t)hi);
-    return (unsigned)a | ((unsigned)b << 16);
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
 }
 
 // pack two accumulator tiles (bf16) / one tile (f32) into an MFMA operand fragment ("acc mapping":
@@ -210,6 +212,30 @@ __device__ __forceinline__ void drop_apply4(const Drop& d, uint32_t base, f32x4&
     v[1] = (h0 >> 16) >= d.thr ? v[1] * d.scale : 0.0f;
     v[2] = (h1 & 0xFFFFu) >= d.thr ? v[2] * d.scale : 0.0f;
     v[3] = (h1 >> 16) >= d.thr ? v[3] * d.scale : 0.0f;
+}
+// v[r] = keep ? v[r] * c : 0 for 4 consecutive elements (c = whatever the caller folds into the 1 / (1 - p)); dropout must be active
+__device__ __forceinline__ void drop_scale4(const Drop& d, uint32_t base, f32x4& v, float c) {
+    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    v[0] = (h0 & 0xFFFFu) >= d.thr ? v[0] * c : 0.0f;
+    v[1] = (h0 >> 16) >= d.thr ? v[1] * c : 0.0f;
+    v[2] = (h1 & 0xFFFFu) >= d.thr ? v[2] * c : 0.0f;
+    v[3] = (h1 >> 16) >= d.thr ? v[3] * c : 0.0f;
+}
+// v[r] = keep ? v[r] : 0 (unscaled); returns the 4 keep bits (bit r); dropout must be active
+__device__ __forceinline__ uint32_t drop_select4(const Drop& d, uint32_t base, f32x4& v) {
+    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    const bool k0 = (h0 & 0xFFFFu) >= d.thr, k1 = (h0 >> 16) >= d.thr, k2 = (h1 & 0xFFFFu) >= d.thr, k3 = (h1 >> 16) >= d.thr;
+    v[0] = k0 ? v[0] : 0.0f; v[1] = k1 ? v[1] : 0.0f; v[2] = k2 ? v[2] : 0.0f; v[3] = k3 ? v[3] : 0.0f;
+    return (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2) | ((uint32_t)k3 << 3);
+}
+// the four bytes of w as floats: v_cvt_f32_ubyte0 .. 3, one instruction each (left to itself the compiler shifts and masks first)
+__device__ __forceinline__ f32x4 ubytes_to_f32x4(uint32_t w) {
+    f32x4 v;
+    asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(v[0]) : "v"(w));
+    asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(v[1]) : "v"(w));
+    asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(v[2]) : "v"(w));
+    asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(v[3]) : "v"(w));
+    return v;
 }
 // ReLU + dropout of 4 consecutive elements in one select each; returns the 4 "kept and positive" bits (bit r)
 __device__ __forceinline__ uint32_t relu_drop_apply4(const Drop& d, uint32_t base, f32x4& v) {

@@ -581,7 +581,7 @@ int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a) {
     return 0;
 }
 
-template <typename T, int KT, bool PAD>
+template <typename T, int KT, bool PAD, bool DROP>
 int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT;
@@ -594,19 +594,20 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
                  (double)n * a.T * a.D * sizeof(T) * (bwd ? 8.0 : 4.0));
     if (!bwd) {
         const size_t smem = 2 * (size_t)TP * G::LD;
-        auto kern = attn_fwd_kernel<T, KT, PAD>;
+        // scheduling-barrier spacing of the score loop: every 5th tile (measured at 160 frames with the packed conversions: 95 us; every tile 119 us)
+        constexpr int SBE = KT >= 3 ? 5 : (KT >= 2 ? 2 : 1);
+        auto kern = attn_fwd_kernel<T, KT, PAD, DROP, SBE>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
-        size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 ? (size_t)TP * (TP / 32) * 4 : 0);
+        size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 && DROP ? (size_t)TP * (TP / 4) : 0);    // + keep bits: a byte per (4 keys, query)
         // Two blocks of >= 5 waves per CU are enough for this kernel (960 x 160 alone: 310 us at 2 blocks per CU, 318-329 at 3, 415 at 1), and the
         // third block only takes registers and LDS from whatever the weight-gradient stream has in flight: a launch that would fit three asks
         // for a little more LDS than a third of the CU's (step 3.785 -> 3.742 ms).  GE2E_ATTN_BWD_3PERCU=1 restores the natural occupancy.
         static const bool three = getenv("GE2E_ATTN_BWD_3PERCU") != nullptr;
         if (!three && nw >= 5 && 3 * smem <= (size_t)160 * 1024) smem = (size_t)160 * 1024 / 3 + 1024;
-        // scheduling-barrier spacing must not exceed the tile-group count of the loops it paces (KT groups in bf16): with the
-        // default 5 the short-T instances (KT <= 4) never hit a barrier, hipcc hoisted every fragment load, 247-256 VGPRs + spills
-        constexpr int SBE = KT >= 5 ? 5 : (KT >= 2 ? 2 : 1);
-        auto kern = attn_bwd_kernel<T, KT, PAD, SBE>;
+        // a scheduling barrier after every tile group (32 keys / queries): 112-120 registers, three blocks per CU fit; spaced wider the
+        // compiler hoists fragment loads (130 registers at 5 groups; 247-256 + spills when a loop never meets a barrier)
+        auto kern = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 2>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     }
     return 0;
@@ -635,18 +636,21 @@ template <typename T>
 int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd, float* delta = nullptr) {
     if (a.T > 32 * MAX_KT) return launch_attn_long<T>(h, st, a, n, bwd, delta);
     const bool pad = a.T % 32 != 0;      // multiples of 32 frames need no key / query masking
+    const bool drop = a.drop.thr != 0;   // dropout is a compile-time property of the kernels (attention.cuh)
+#define launch_attn_kt(TT, KK, PP) (drop ? launch_attn_kt<TT, KK, PP, true>(h, st, a, n, bwd) : launch_attn_kt<TT, KK, PP, false>(h, st, a, n, bwd))
     switch ((a.T + 31) / 32) {
-        case 1: return pad ? launch_attn_kt<T, 1, true>(h, st, a, n, bwd) : launch_attn_kt<T, 1, false>(h, st, a, n, bwd);
-        case 2: return pad ? launch_attn_kt<T, 2, true>(h, st, a, n, bwd) : launch_attn_kt<T, 2, false>(h, st, a, n, bwd);
-        case 3: return pad ? launch_attn_kt<T, 3, true>(h, st, a, n, bwd) : launch_attn_kt<T, 3, false>(h, st, a, n, bwd);
-        case 4: return pad ? launch_attn_kt<T, 4, true>(h, st, a, n, bwd) : launch_attn_kt<T, 4, false>(h, st, a, n, bwd);
-        case 5: return pad ? launch_attn_kt<T, 5, true>(h, st, a, n, bwd) : launch_attn_kt<T, 5, false>(h, st, a, n, bwd);
-        case 6: return pad ? launch_attn_kt<T, 6, true>(h, st, a, n, bwd) : launch_attn_kt<T, 6, false>(h, st, a, n, bwd);
-        case 7: return pad ? launch_attn_kt<T, 7, true>(h, st, a, n, bwd) : launch_attn_kt<T, 7, false>(h, st, a, n, bwd);
-        case 8: return pad ? launch_attn_kt<T, 8, true>(h, st, a, n, bwd) : launch_attn_kt<T, 8, false>(h, st, a, n, bwd);
-        case 9: return pad ? launch_attn_kt<T, 9, true>(h, st, a, n, bwd) : launch_attn_kt<T, 9, false>(h, st, a, n, bwd);
+        case 1: return pad ? launch_attn_kt(T, 1, true) : launch_attn_kt(T, 1, false);
+        case 2: return pad ? launch_attn_kt(T, 2, true) : launch_attn_kt(T, 2, false);
+        case 3: return pad ? launch_attn_kt(T, 3, true) : launch_attn_kt(T, 3, false);
+        case 4: return pad ? launch_attn_kt(T, 4, true) : launch_attn_kt(T, 4, false);
+        case 5: return pad ? launch_attn_kt(T, 5, true) : launch_attn_kt(T, 5, false);
+        case 6: return pad ? launch_attn_kt(T, 6, true) : launch_attn_kt(T, 6, false);
+        case 7: return pad ? launch_attn_kt(T, 7, true) : launch_attn_kt(T, 7, false);
+        case 8: return pad ? launch_attn_kt(T, 8, true) : launch_attn_kt(T, 8, false);
+        case 9: return pad ? launch_attn_kt(T, 9, true) : launch_attn_kt(T, 9, false);
         default: return fail(h, GE2E_EUNSUPPORTED, "attention: frame count not instantiated");
     }
+#undef launch_attn_kt
 }
 
 // last layer: one query per utterance, no K / V projection (attn_last.cuh)

@@ -228,8 +228,8 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     delta = (do_h * o_h).sum(-1, keepdim=True)                          # = sum_k P dP, formed from the SAVED (rounded) O as the kernel does
     dpd = (do_h @ sv["v"].transpose(-1, -2)) * keep_a * scale_d
     ds = rt(prob * (dpd - delta) / 8.0, prec)                           # dS and the dropped P are packed to the storage type
-    pdr = rt(prob * keep_a * scale_d, prec)
-    dq, dk, dv = ds @ sv["k"], ds.transpose(-1, -2) @ sv["q"], pdr.transpose(-1, -2) @ do_h
+    pdr = rt(prob * keep_a, prec)                                       # (the kept probabilities are packed UNSCALED; 1 / (1 - p) goes on the finished dV)
+    dq, dk, dv = ds @ sv["k"], ds.transpose(-1, -2) @ sv["q"], (pdr.transpose(-1, -2) @ do_h) * scale_d
     dqkv_ref = torch.cat([z.permute(0, 2, 1, 3).reshape(R, d) for z in (dq, dk, dv)], dim=1)
     dQKV = tap(f"dQKV.{l}", (R, 3 * d))
     close(dQKV, dqkv_ref, prec, "attention backward (attn_bwd_kernel)", l2=0.4, ulps=6.0)

@@ -21,8 +21,8 @@ __global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
 }
 template <int SBE> void run(const AttnArgs& a, int n, const char* tag) {
     using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    const size_t sf = 2 * (size_t)TP * G::LD, sb = sf + 2 * TP * 4 + TP * (TP / 32) * 4;
-    auto kf = attn_fwd_kernel<T, KT, false, SBE>; auto kb = attn_bwd_kernel<T, KT, false, SBE>;
+    const size_t sf = 2 * (size_t)TP * G::LD, sb = sf + 2 * TP * 4 + TP * (TP / 4);
+    auto kf = attn_fwd_kernel<T, KT, false, true, SBE>; auto kb = attn_bwd_kernel<T, KT, false, true, SBE>;
     CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
     float f = time_kernel([&]() { hipLaunchKernelGGL(kf, dim3(n * 4), dim3(320), sf, 0, a); });

@@ -1,13 +1,14 @@
+#pragma once
+#include "common.cuh"
 // Fused self-attention of one (utterance, head): SURVEY.md 8a row a4 and its backward (a13).
 //
 // The whole key/value sequence of a head (T <= 32*KT frames, 64 dims) is LDS-resident; a wave owns
 // 16 query rows at a time.  Scores are computed TRANSPOSED (S^T = K Q^T) so that a query's row of
 // probabilities lives on one lane quartet and the probability accumulators feed the P.V MFMAs
 // directly as operands (no LDS round trip; guide section 3 "accumulator tile as the next operand").
-#pragma once
 #include "common.cuh"
 
-namespace ge2e {
+namespace ge2e { namespace v0 {
 
 struct AttnArgs {
     const void* qkv;     // [R, 3*D] of T : q | k | v, head h at columns h*64
@@ -98,11 +99,8 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
 }
 }  // namespace attn
 
-// DROP is a COMPILE-TIME switch (the launcher tests drop.thr): as a run-time test of drop.thr inside the tile loops it split every
-// tile (forward, phase A) or every ELEMENT (phase B: a mask read from LDS, its wait and a branch per probability) into a basic block
-// of its own.
-// ABL (development only, tools/attn_bwd_bench.hip): 1 no compute (tile loads + barrier only), 4 no exp, 8 no P.V
-template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 1, int ABL = 0>
+// ABL (development only, tools/attn_bwd_bench.hip): 1 no compute (tile loads + barrier only), 2 no dropout, 4 no exp, 8 no P.V
+template <typename T, int KT, bool PAD = true, int SBE = 1, int ABL = 0>
 __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
@@ -143,14 +141,14 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = (ABL & 4) ? s[t][r] * ck - mk : ExpK<T>::ex(s[t][r] * ck - mk); s[t][r] = e; sum += e; }
         const float tot = cross4_sum(sum);
-        const float inv = DROP ? p.drop.scale / tot : 1.0f / tot;       // normalisation and 1 / (1 - p) as ONE factor
+        const float inv = 1.0f / tot;
         if (p.lse && g == 0 && vq) p.lse[((size_t)n * p.T + qrow) * p.H + h] = mx * p.scale + logf(tot);
         // dropout counter of P[query][key] = (head_row * T + query) * T4 + key, T4 = T rounded up to 4 (aligned quads)
         const uint32_t ibase = ((uint32_t)blockIdx.x * (uint32_t)p.T + (uint32_t)qrow) * (uint32_t)((p.T + 3) & ~3);
 #pragma unroll
-        for (int t = 0; t < NT16; ++t) {
-            if constexpr (DROP) drop_scale4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t], inv);
-            else s[t] *= inv;
+        for (int t = 0; t < NT16; ++t) { const int sb_i = t;
+            s[t] *= inv;
+            if (!(ABL & 2)) drop_apply4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), s[t]);
         }
 
         f32x4 oacc[4];
@@ -177,25 +175,21 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 // every 16x16 tile of P and dS is a pure function of its own scores.
 //   Phase A (wave owns 16 queries; K, V in LDS): delta -> LDS, dQ^T += K^T dS^T.
 //   Phase B (wave owns 16 keys;    Q, dO in LDS): dV^T += dO^T Pd, dK^T += Q^T dS.
-// With dropout, dS = P (keep dP / (1 - p) - delta) scale is evaluated as P . fma(keep ? dP : 0, scale / (1 - p), - delta scale), and dV
-// accumulates the UNSCALED kept probabilities (its 1 / (1 - p) is applied once to the finished accumulators).
-// MINB: blocks per CU the register allocation must allow (launch bound).
-// ABL (development only, tools/attn_bwd_bench.hip): 1 no phase B, 2 no phase A, 8 no exp
-template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 5, int ABL = 0, int MINB = 1>
-__global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
+// ABL (development only, tools/attn_bwd_bench.hip): 1 no phase B, 2 no phase A, 4 no dropout work, 8 no exp
+template <typename T, int KT, bool PAD = true, int SBE = 5, int ABL = 0>
+__global__ void __launch_bounds__(512) attn_bwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const bufA = smem;
     unsigned char* const bufB = smem + TP * G::LD;
     float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse (times ExpK) per query of this head
-    float* const st_d = st_l + TP;                            // delta * scale per query
-    // The 16-bit modes hash the dropout keep bits once (phase A) and hand them to phase B through LDS; fp32 mode (parity
-    // path; its K/V tiles already fill the LDS at 288 frames) re-hashes in phase B instead.  One BYTE per (4 keys, query), key
-    // quad major: phase A's lane (keys 16t + 4g .. + 3, query) stores its nibble as one byte, no atomics and no clearing; phase B's
-    // lane (queries 16t + 4g .. + 3, key) finds its four bytes in ONE word.
+    float* const st_d = st_l + TP;                            // delta per query
+    // bf16 mode hashes the dropout keep bits once (phase A) and hands them to phase B through LDS; fp32 mode (parity
+    // path; its K/V tiles already fill the LDS at 288 frames) re-hashes in phase B instead
     constexpr bool USE_MASK = sizeof(T) == 2;
-    unsigned char* const st_m = (unsigned char*)(st_d + TP);  // [TP / 4][TP]
+    constexpr int MW = TP / 32;                               // keep-mask words per query row
+    uint32_t* const st_m = (uint32_t*)(st_d + TP);            // [TP][MW] dropout keep bits, filled by phase A
     const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int i = lane & 15, g = lane >> 4;
@@ -216,8 +210,9 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
         st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
         st_d[q] = 0.0f;          // padded queries: phase B multiplies (dP - delta) by P = 0, so delta must be finite
     }
+    const bool dropping = (ABL & 4) ? false : p.drop.thr != 0;
+    if (USE_MASK && dropping) for (int q = threadIdx.x; q < TP * MW; q += blockDim.x) st_m[q] = 0u;
     const float ck = p.scale * ExpK<T>::K;
-    const float sds = DROP ? p.scale * p.drop.scale : p.scale;
     __syncthreads();
     for (int qt = wave; qt * 16 < p.T && !(ABL & 2); qt += nw) {
         const int qrow = qt * 16 + i;
@@ -237,8 +232,8 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                 for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
             }
         }
-        const float dsc = cross4_sum(delta) * p.scale;
-        if (g == 0 && vq) st_d[qrow] = dsc;
+        delta = cross4_sum(delta);
+        if (g == 0 && vq) st_d[qrow] = delta;
         const float lse = st_l[vq ? qrow : 0];
         const uint32_t ibase = (hbase + (uint32_t)qrow) * T4;
         f32x4 qacc[4];
@@ -253,15 +248,17 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                 const int t = gi * TPG + u;
                 const f32x4 sa = attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
                 f32x4 dp = attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
-                if constexpr (DROP) {      // keep bits are hashed once, here; phase B reads them back from LDS
-                    const uint32_t m = drop_select4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp);
-                    if constexpr (USE_MASK) st_m[(4 * t + g) * TP + qrow] = (unsigned char)m;
+                if (dropping) {      // keep bits are hashed once, here; phase B reads them back from LDS
+                    const uint32_t m = drop_mask4(p.drop, ibase + (uint32_t)(16 * t + 4 * g));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[r] = ((m >> r) & 1u) ? dp[r] * p.drop.scale : 0.0f;
+                    if (USE_MASK && vq) atomicOr(st_m + qrow * MW + ((16 * t + 4 * g) >> 5), m << ((16 * t + 4 * g) & 31));
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float pr = (ABL & 8) ? sa[r] * ck - lse : ExpK<T>::ex(sa[r] * ck - lse);
                     if (PAD && (16 * t + 4 * g + r) >= p.T) pr = 0.0f;
-                    ds[u][r] = pr * (dp[r] * sds - dsc);
+                    ds[u][r] = pr * (dp[r] - delta) * p.scale;
                 }
             }
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
@@ -290,9 +287,6 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
         f32x4 kacc[4], vacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
-        // this key's keep bits of queries 16t + 4g + r: byte r of word [krow / 4][16t + 4g], bit krow % 4
-        [[maybe_unused]] const unsigned char* const mrow = st_m + (krow >> 2) * TP + 4 * g;
-        [[maybe_unused]] const int mbit = krow & 3;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int sb_i = gi;
@@ -304,8 +298,6 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                 const f32x4 da = attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
                 const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
                 const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
-                [[maybe_unused]] f32x4 keep4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
-                if constexpr (DROP && USE_MASK) keep4 = ubytes_to_f32x4((*(const uint32_t*)(mrow + 16 * t) >> mbit) & 0x01010101u);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int q = 16 * t + 4 * g + r;
@@ -313,14 +305,13 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                     if (PAD && !((q < p.T) && vk)) pr = 0.0f;
                     float dv = da[r];
                     pd[u][r] = pr;
-                    if constexpr (DROP) {
-                        // keep as a 0.0 / 1.0 factor (v_cvt_f32_ubyte<r>): one conversion and two multiplies per element
-                        const float keep = USE_MASK ? keep4[r]
-                                                    : (drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr) ? 1.0f : 0.0f);
-                        dv *= keep;
-                        pd[u][r] = pr * keep;
+                    if (dropping) {
+                        const bool keep = USE_MASK ? (bool)((st_m[q * MW + (krow >> 5)] >> (krow & 31)) & 1u)
+                                                   : drop_keep((hbase + (uint32_t)q) * T4 + (uint32_t)krow, p.drop.key, p.drop.thr);
+                        dv = keep ? dv * p.drop.scale : 0.0f;
+                        pd[u][r] = keep ? pr * p.drop.scale : 0.0f;
                     }
-                    ds[u][r] = (PAD && pr == 0.0f) ? 0.0f : pr * (dv * sds - d4[r]);
+                    ds[u][r] = (PAD && pr == 0.0f) ? 0.0f : pr * (dv - d4[r]) * p.scale;
                 }
             }
             const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);
@@ -331,10 +322,6 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                 kacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
             }
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
-        }
-        if constexpr (DROP) {
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) vacc[dt] *= p.drop.scale;
         }
         if (vk) {
             T* row = dq_out + (size_t)krow * 3 * p.D + 4 * g;
@@ -594,4 +581,4 @@ __global__ void __launch_bounds__(256) attn_bwd_long_dkv_kernel(const AttnArgs p
 
 // (The last layer's single-query attention lives in attn_last.cuh: it needs no K / V projection at all.)
 
-}  // namespace ge2e
+} }  // namespace ge2e::v0
