@@ -143,11 +143,22 @@ def drop_threshold(p: float) -> int:
     return int(math.floor(p * 65536.0))
 
 
+def _xs32(x):
+    """one xorshift32 step (13, 17, 5)"""
+    x = x.astype(np.uint64)
+    x ^= (x << np.uint64(13)) & _M32
+    x ^= x >> np.uint64(17)
+    x ^= (x << np.uint64(5)) & _M32
+    return x.astype(np.uint32)
+
+
 def drop_keep_at(key: int, idx, p: float):
-    """keep[idx]: word = mix32((idx >> 1) ^ key); field = word >> 16 if idx odd else word & 0xFFFF;
-    keep = field >= floor(p * 2^16).  One hash serves an index pair (see csrc/common.cuh)."""
+    """keep[idx]: w0 = mix32((idx >> 2) ^ key), w1 = xs32(w0); word = w1 if idx & 2 else w0;
+    field = word >> 16 if idx odd else word & 0xFFFF; keep = field >= floor(p * 2^16).
+    One multiplicative hash serves an aligned index quad (see csrc/common.cuh)."""
     idx = np.asarray(idx, dtype=np.uint64)
-    w = _mix32(((idx >> np.uint64(1)) ^ np.uint64(key)) & _M32)
+    w0 = _mix32(((idx >> np.uint64(2)) ^ np.uint64(key)) & _M32)
+    w = np.where((idx & np.uint64(2)).astype(bool), _xs32(w0), w0)
     field = np.where((idx & np.uint64(1)).astype(bool), w >> np.uint32(16), w & np.uint32(0xFFFF))
     return field >= np.uint32(drop_threshold(p))
 

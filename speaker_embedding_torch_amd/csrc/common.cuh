@@ -176,17 +176,22 @@ template <> __device__ __forceinline__ u32x4 frag_tr<bf16_t>(const unsigned char
 template <> __device__ __forceinline__ u32x4 frag_tr<f16_t>(const unsigned char* tile, int ld, int r0, int c0, int lane) { return frag_tr16(tile, ld, r0, c0, lane); }
 
 // ---------------------------------------------------------------------------------------------
-// counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep.  One 32-bit hash serves the
-// two elements of an index pair (v_mul_lo_u32 is quarter rate, so hashes are the cost):
-//   word(idx) = mix32((idx >> 1) ^ key);  field = idx odd ? word >> 16 : word & 0xFFFF;
+// counter-based dropout, bit-identical to oracle/ge2e_oracle.py: drop_keep.  ONE multiplicative hash serves the four elements of
+// an aligned index quad (its two v_mul_lo_u32 are quarter rate: the hashes are what dropout costs, and the kernels that apply it are
+// bound by their vector instructions); the quad's second word is one xorshift32 step of the first (six full-rate instructions):
+//   w0 = mix32((idx >> 2) ^ key), w1 = xs32(w0);  word = idx & 2 ? w1 : w0;  field = idx & 1 ? word >> 16 : word & 0xFFFF;
 //   keep(idx) = field >= thr,  thr = floor(p * 65536)
+// (rounds 1-2 hashed every index PAIR; keep rates, the 16 joint keep patterns of a quad and the lag correlations between quads are
+// within sampling noise of independent draws over 2^24 quads: tests/test_host_glue.py)
 // ---------------------------------------------------------------------------------------------
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
+__host__ __device__ __forceinline__ uint32_t xs32(uint32_t x) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; }
 __host__ __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t key, uint32_t thr) {
-    const uint32_t w = mix32((idx >> 1) ^ key);
+    uint32_t w = mix32((idx >> 2) ^ key);
+    if (idx & 2u) w = xs32(w);
     return ((idx & 1u) ? (w >> 16) : (w & 0xFFFFu)) >= thr;
 }
 struct Drop {            // thr == 0  <=>  dropout inactive (eval mode or p == 0)
@@ -197,9 +202,9 @@ __device__ __forceinline__ float drop_apply(const Drop& d, uint32_t idx, float v
     if (d.thr == 0) return v;
     return drop_keep(idx, d.key, d.thr) ? v * d.scale : 0.0f;
 }
-// keep-mask (bit r <-> element base + r) of 4 consecutive elements, base % 4 == 0: two hashes
+// keep-mask (bit r <-> element base + r) of 4 consecutive elements, base % 4 == 0
 __device__ __forceinline__ uint32_t drop_mask4(const Drop& d, uint32_t base) {
-    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    const uint32_t h0 = mix32((base >> 2) ^ d.key), h1 = xs32(h0);
     return (uint32_t)((h0 & 0xFFFFu) >= d.thr) | ((uint32_t)((h0 >> 16) >= d.thr) << 1) |
            ((uint32_t)((h1 & 0xFFFFu) >= d.thr) << 2) | ((uint32_t)((h1 >> 16) >= d.thr) << 3);
 }
@@ -207,7 +212,7 @@ __device__ __forceinline__ uint32_t drop_mask4(const Drop& d, uint32_t base) {
 // building the 4-bit mask of drop_mask4 in a VGPR and testing its bits again costs ~2x the VALU of this form
 __device__ __forceinline__ void drop_apply4(const Drop& d, uint32_t base, f32x4& v) {
     if (d.thr == 0) return;
-    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    const uint32_t h0 = mix32((base >> 2) ^ d.key), h1 = xs32(h0);
     v[0] = (h0 & 0xFFFFu) >= d.thr ? v[0] * d.scale : 0.0f;
     v[1] = (h0 >> 16) >= d.thr ? v[1] * d.scale : 0.0f;
     v[2] = (h1 & 0xFFFFu) >= d.thr ? v[2] * d.scale : 0.0f;
@@ -215,7 +220,7 @@ __device__ __forceinline__ void drop_apply4(const Drop& d, uint32_t base, f32x4&
 }
 // v[r] = keep ? v[r] * c : 0 for 4 consecutive elements (c = whatever the caller folds into the 1 / (1 - p)); dropout must be active
 __device__ __forceinline__ void drop_scale4(const Drop& d, uint32_t base, f32x4& v, float c) {
-    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    const uint32_t h0 = mix32((base >> 2) ^ d.key), h1 = xs32(h0);
     v[0] = (h0 & 0xFFFFu) >= d.thr ? v[0] * c : 0.0f;
     v[1] = (h0 >> 16) >= d.thr ? v[1] * c : 0.0f;
     v[2] = (h1 & 0xFFFFu) >= d.thr ? v[2] * c : 0.0f;
@@ -223,7 +228,7 @@ __device__ __forceinline__ void drop_scale4(const Drop& d, uint32_t base, f32x4&
 }
 // v[r] = keep ? v[r] : 0 (unscaled); returns the 4 keep bits (bit r); dropout must be active
 __device__ __forceinline__ uint32_t drop_select4(const Drop& d, uint32_t base, f32x4& v) {
-    const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+    const uint32_t h0 = mix32((base >> 2) ^ d.key), h1 = xs32(h0);
     const bool k0 = (h0 & 0xFFFFu) >= d.thr, k1 = (h0 >> 16) >= d.thr, k2 = (h1 & 0xFFFFu) >= d.thr, k3 = (h1 >> 16) >= d.thr;
     v[0] = k0 ? v[0] : 0.0f; v[1] = k1 ? v[1] : 0.0f; v[2] = k2 ? v[2] : 0.0f; v[3] = k3 ? v[3] : 0.0f;
     return (uint32_t)k0 | ((uint32_t)k1 << 1) | ((uint32_t)k2 << 2) | ((uint32_t)k3 << 3);
@@ -244,7 +249,7 @@ __device__ __forceinline__ uint32_t relu_drop_apply4(const Drop& d, uint32_t bas
 #pragma unroll
         for (int r = 0; r < 4; ++r) { on[r] = v[r] > 0.0f; v[r] = on[r] ? v[r] : 0.0f; }
     } else {
-        const uint32_t h0 = mix32((base >> 1) ^ d.key), h1 = mix32(((base >> 1) + 1u) ^ d.key);
+        const uint32_t h0 = mix32((base >> 2) ^ d.key), h1 = xs32(h0);
         on[0] = v[0] > 0.0f && (h0 & 0xFFFFu) >= d.thr;
         on[1] = v[1] > 0.0f && (h0 >> 16) >= d.thr;
         on[2] = v[2] > 0.0f && (h1 & 0xFFFFu) >= d.thr;

@@ -182,3 +182,21 @@ def test_trainer_launcher_command_line():
     assert "--nproc-per-node=4" in cmd and "torch.distributed.run" in cmd and cmd[-2:] == ["-hp", "x.yaml"]
     assert "127.0.0.1" in cmd and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert os.access(os.path.join(REPO, "multi_gpu.sh"), os.X_OK)
+
+
+def test_dropout_stream_keep_rate_and_independence_inside_a_quad():
+    """The dropout stream hashes an aligned index QUAD once (mix32) and takes the quad's second word from one xorshift32 step
+    (csrc/common.cuh, oracle drop_keep_at).  Over 2^20 quads: keep rate of each of the four positions, the 16 joint keep patterns of
+    a quad against independent draws, and the correlation between neighbouring quads."""
+    from oracle import ge2e_oracle as O
+    nq = 1 << 20
+    for key, p in ((0x12345678, 0.1), (O.drop_key(1234, 7, 3), 0.5)):
+        keep = O.drop_keep(key, 4 * nq, p).reshape(nq, 4)
+        pk = 1.0 - O.drop_threshold(p) / 65536.0
+        assert np.abs(keep.mean(0) - pk).max() < 4.5 * np.sqrt(pk * (1 - pk) / nq)
+        code = (keep * np.array([1, 2, 4, 8])).sum(1)
+        freq = np.bincount(code, minlength=16) / nq
+        exp = np.array([np.prod([pk if (c >> b) & 1 else 1 - pk for b in range(4)]) for c in range(16)])
+        assert (np.abs(freq - exp) / np.sqrt(exp * (1 - exp) / nq)).max() < 4.5
+        for a, b in ((3, 0), (0, 0), (2, 2)):          # position a of quad q against position b of quad q + 1
+            assert abs(np.corrcoef(keep[:-1, a], keep[1:, b])[0, 1]) < 4.5 / np.sqrt(nq)
