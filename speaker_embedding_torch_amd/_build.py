@@ -15,6 +15,10 @@ LIB = os.path.join(PKG, "libge2e_hip.so")
 STAMP = LIB + ".hash"
 HEADER = os.path.normpath(os.path.join(PKG, "..", "include", "ge2e_hip.h"))
 SOURCES = ["ge2e_capi.hip"]
+# -fno-slp-vectorize: left on, the compiler pairs neighbouring fp32 multiplies / adds into v_pk_mul_f32 / v_pk_fma_f32, which cost more
+# issue time than the two scalar instructions they replace when MFMAs share the SIMD (MI355X_MICROARCH.md, "packed f32 VALU ... an
+# anti-lever beside MFMAs"): same-box A/B of the training step 3.647 -> 3.607 ms.  The flags are part of the source hash.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-fno-slp-vectorize"]
 
 
 def dependencies():
@@ -24,6 +28,7 @@ def dependencies():
 
 def source_hash():
     h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode() + b"\0")
     for path in dependencies():
         h.update(os.path.basename(path).encode() + b"\0")
         with open(path, "rb") as f:
@@ -50,8 +55,7 @@ def build(force=False, verbose=False):
         return LIB
     digest = source_hash()
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           f'-DGE2E_SOURCE_HASH="{digest}"', "-o", LIB + ".tmp"]
+    cmd = [hipcc] + FLAGS + [f'-DGE2E_SOURCE_HASH="{digest}"', "-o", LIB + ".tmp"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

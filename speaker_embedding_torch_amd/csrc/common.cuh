@@ -86,6 +86,15 @@ __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, f16x2_t));
 }
 
+template <typename T> __device__ __forceinline__ unsigned pack2(float lo, float hi);
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float lo, float hi) { return pack_bf16x2(lo, hi); }
+template <> __device__ __forceinline__ unsigned pack2<f16_t>(float lo, float hi) { return pack_f16x2(lo, hi); }
+// elements e0 .. e0 + 3 (e0 % 4 == 0) of a 16-byte fragment of T from 4 floats
+template <typename T> __device__ __forceinline__ void frag_put4(u32x4& f, int e0, f32x4 v) {
+    if constexpr (sizeof(T) == 2) { f[e0 >> 1] = pack2<T>(v[0], v[1]); f[(e0 >> 1) + 1] = pack2<T>(v[2], v[3]); }
+    else { f[0] = __float_as_uint(v[0]); f[1] = __float_as_uint(v[1]); f[2] = __float_as_uint(v[2]); f[3] = __float_as_uint(v[3]); }
+}
+
 // pack two accumulator tiles (bf16) / one tile (f32) into an MFMA operand fragment ("acc mapping":
 // slot j<4 <-> row 4g+j of tile 0, slot 4+j <-> row 4g+j of tile 1 (bf16); slot s <-> row 4g+s (f32)).
 template <typename T> __device__ __forceinline__ u32x4 pack_acc(f32x4 t0, f32x4 t1);

@@ -79,7 +79,6 @@ __global__ void __launch_bounds__(256) prenet_bwd_kernel(const PrenetBwdArgs p) 
             const T* src = (const T*)&ry[q];
             const float* pe = p.pe_t + (size_t)(gr < rend ? gr % p.T : 0) * 256 + col;
             u32x4 out;
-            T* dst = (T*)&out;
 #pragma unroll
             for (int e0 = 0; e0 < FR; e0 += 4) {
                 f32x4 d = f32x4{to_f32(src[e0]), to_f32(src[e0 + 1]), to_f32(src[e0 + 2]), to_f32(src[e0 + 3])};
@@ -87,7 +86,8 @@ __global__ void __launch_bounds__(256) prenet_bwd_kernel(const PrenetBwdArgs p) 
                 const f32x4 pe4 = *(const f32x4*)(pe + e0);
                 dal += (d[0] * pe4[0] + d[1] * pe4[1]) + (d[2] * pe4[2] + d[3] * pe4[3]);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dst[e0 + r] = from_f32<T>(((bits >> (e0 + r)) & 1u) ? d[r] : 0.0f);
+                for (int r = 0; r < 4; ++r) d[r] = ((bits >> (e0 + r)) & 1u) ? d[r] : 0.0f;
+                frag_put4<T>(out, e0, d);              // (pairs leave through ONE packed conversion each)
             }
             *(u32x4*)(y + row * LD + c * 16) = out;
             *(u32x4*)(x + row * LD + c * 16) = rx[q];
