@@ -251,6 +251,23 @@ __device__ __forceinline__ f32x4 ubytes_to_f32x4(uint32_t w) {
     asm("v_cvt_f32_ubyte3 %0, %1" : "=v"(v[3]) : "v"(w));
     return v;
 }
+// On PACKED 16-bit pairs (bf16 or fp16 alike: sign bit on top).  ReLU: the signed 16-bit maximum against 0 clears every value whose sign
+// bit is set (negative numbers and -0), one instruction per pair.
+__device__ __forceinline__ uint32_t pk_relu16(uint32_t v) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(v));
+    return r;
+}
+// Dropout of a pair by the two 16-bit fields of its hash word w (low field <-> low element): field >= thr  <=>  the saturating
+// difference field - (thr - 1) is non-zero; clamped to 1 it is the factor of an integer multiply of the pair.  tt = (thr - 1) in both
+// halves, thr >= 1.  Three instructions per pair, no compares, no selects.
+__device__ __forceinline__ uint32_t pk_keep16(uint32_t v, uint32_t w, uint32_t tt) {
+    uint32_t d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(w), "v"(tt));
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(d), "s"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(d) : "v"(v), "v"(d));
+    return d;
+}
 // ReLU + dropout of 4 consecutive elements in one select each; returns the 4 "kept and positive" bits (bit r)
 __device__ __forceinline__ uint32_t relu_drop_apply4(const Drop& d, uint32_t base, f32x4& v) {
     bool on[4];

@@ -92,7 +92,7 @@ template <int WV> constexpr size_t ffn_smem() { return (size_t)ffn_nstg<WV>() * 
 template <int WV> constexpr size_t ffn_bwd_smem() { return ffn_smem<WV>() + (size_t)WV * 2 * 2 * 256; }
 
 // grid = persistent blocks of 512 threads, one per CU at most, sized so that every block runs the same number of passes
-// ABL (development only, tools/ffn_bench.hip): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no barrier, 16 no hidden epilogue
+// ABL (development only, tools/ffn_bench.hip): 1 no MFMA, 2 no DMA, 4 no fragment reads, 8 no barrier, 16 no hidden epilogue, 128 no hidden store
 // STAGGER: waves 4-7 lag by one product (see the stage loop).  Measured at 153,600 rows: train (dropout hashes + hidden store in the
 // hidden epilogue) 310 -> 279 us with it, eval (a light epilogue) 215 -> 243 us: the launcher staggers train mode only.
 template <typename T, bool STORE_F, int ABL = 0, bool STAGGER = STORE_F, int WV = 8, bool BWD = false>
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
     constexpr int NCH = FFN_F / 32;              // stages per pass
     constexpr int NSTG = ffn_nstg<WV>(), D = NSTG - 1;
     constexpr int NDMA = 32 / WV;                // DMA instructions per wave and stage
-    constexpr int NST = STORE_F ? 2 : 0;         // hidden-store instructions per wave and stage that the counted waits rely on (the two
+    constexpr int NST = STORE_F && !(ABL & 128) ? 2 : 0;   // hidden-store instructions per wave and stage that the counted waits rely on (the two
                                                  // 16-byte value stores; every fourth stage adds two mask words: a count may be too small)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Ring = smem;                                      // [NSTG][32 KB]: W1 slice | W2 slice
@@ -122,7 +122,8 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
     if constexpr (BWD) {
         if (tid < 256) { const float gq = p.gamma[tid]; Ls[tid] = gq; Ls[256 + tid] = p.beta[tid]; Ls[512 + tid] = gq != 0.0f ? 1.0f / gq : 0.0f; }
     } else {
-    for (int q = tid; q < FFN_F; q += 64 * WV) B1s[q] = p.b1[q];
+    // (train: the bias table is pre-multiplied by dropout1's 1 / (1 - p): the hidden epilogue forms (acc + b) / (1 - p) as ONE fma per element)
+    for (int q = tid; q < FFN_F; q += 64 * WV) B1s[q] = p.b1[q] * (STORE_F ? p.drop1.scale : 1.0f);
     if (tid < 256) { Ls[tid] = p.b2[tid]; Ls[256 + tid] = p.gamma[tid]; Ls[512 + tid] = p.beta[tid]; }
     }
     __syncthreads();                              // no DMA in flight yet: an ordinary barrier
@@ -405,26 +406,41 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                     for (int ht = 0; ht < 2; ++ht)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h[rt][ht][r] = ((by >> (4 * ht + r)) & 1u) ? h[rt][ht][r] * p.drop1.scale : 0.0f;
-                } else {
+                } else if constexpr ((ABL & 16) == 0) {
+                    // (acc + b1) / (1 - p) in fp32, one fma per element (eval: the factor is 1); the ReLU and the dropout then act on the
+                    // PACKED 16-bit pairs: a negative value has its sign bit set, so a packed signed max against 0 is the ReLU (one
+                    // instruction per pair), and the pair's two keep decisions are the two 16-bit fields of one hash word (pk_keep)
+                    const float sc = STORE_F ? p.drop1.scale : 1.0f;
 #pragma unroll
-                for (int ht = 0; ht < 2; ++ht) {
-                    const int col = c * 32 + 8 * g + 4 * ht;
-                    if constexpr ((ABL & 16) == 0) {
-                    h[rt][ht] += *(const f32x4*)(smem + bb + 16 * ht);
-                    if constexpr (STORE_F) (void)relu_drop_apply4(p.drop1, (uint32_t)row * drm * (uint32_t)FFN_F + (uint32_t)col, h[rt][ht]);
-                    else (void)relu_drop_apply4(Drop{0u, 0u, 1.0f}, 0u, h[rt][ht]);      // the eval kernel: no dropout (the launcher checks)
+                    for (int ht = 0; ht < 2; ++ht) {
+                        const f32x4 b4 = *(const f32x4*)(smem + bb + 16 * ht);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[rt][ht][r] = __builtin_fmaf(h[rt][ht][r], sc, b4[r]);
                     }
                 }
-                }
                 hp[rt] = pack_acc<T>(h[rt][0], h[rt][1]);      // 8 consecutive hidden units 32c + 8g .. + 7 of row (rt, i)
-                if constexpr (STORE_F) {
+                if constexpr (!BWD && (ABL & 16) == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hp[rt][k] = pk_relu16(hp[rt][k]);
+                    if constexpr (STORE_F) {
+                        if (p.drop1.thr != 0) {            // (uniform; the eval kernel has no dropout: the launcher checks)
+                            const uint32_t q0 = ((uint32_t)row * drm * (uint32_t)FFN_F + (uint32_t)(c * 32 + 8 * g)) >> 2;     // two aligned index quads
+                            const uint32_t w0 = mix32(q0 ^ p.drop1.key), w2 = mix32((q0 + 1u) ^ p.drop1.key);
+                            const uint32_t tt = (p.drop1.thr - 1u) * 0x00010001u;
+                            hp[rt][0] = pk_keep16(hp[rt][0], w0, tt); hp[rt][1] = pk_keep16(hp[rt][1], xs32(w0), tt);
+                            hp[rt][2] = pk_keep16(hp[rt][2], w2, tt); hp[rt][3] = pk_keep16(hp[rt][3], xs32(w2), tt);
+                        }
+                    }
+                }
+                if constexpr (STORE_F && !(ABL & 128)) {
                     if (row < p.M) {       // 32-bit offset in 16-byte units (rows x F x 2 B stays below 2^36 B for every shape the library accepts)
                         unsigned fo = (unsigned)row * (unsigned)(p.ldf >> 3) + (unsigned)(4 * c + g);
+                        if constexpr (ABL & 256) fo = (unsigned)(threadIdx.x + 256 * (blockIdx.x & 63));      // ablation: every store into one small cached region
                         asm volatile("" : "+v"(fo));
                         __builtin_nontemporal_store(hp[rt], (u32x4*)((unsigned char*)Fg + (size_t)fo * 16));
                     }
                 }
-                if constexpr (STORE_F && !BWD) {
+                if constexpr (STORE_F && !BWD && !(ABL & 128)) {
                     // "stored value != 0" of the 8 packed 16-bit values (they are +0 or positive): a packed min against 1 leaves
                     // bit 0 / bit 16 of word k for units 2k / 2k + 1 (building the bits from the compares costs twice the VALU)
                     uint32_t tb = 0;

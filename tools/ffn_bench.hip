@@ -64,6 +64,11 @@ int main(int argc, char** argv) {
     run<true, 8, 4>("train 4-wave no barrier", ad, 400);
     run<true, 16, 4>("train 4-wave no hidden epilogue math", ad, 400);
     run<true, 64, 4>("train 4-wave no pass epilogue", ad, 400);
+    run<true, 128, 4>("train 4-wave no hidden store", ad, 512);
+    run<true, 256, 4>("train 4-wave hidden stores into a cached 256 KB", ad, 512);
+    run<true, 144, 4>("train 4-wave no hidden store, no epilogue math", ad, 512);
+    run<true, 16, 4>("train 4-wave no hidden epilogue math", ad, 512);
+    run<true, 0, 4>("train 4-wave", ad, 512);
     run<true, 0>("train full (dropout on, hidden stored)", ad, 256);
     run<true, 0>("train full, 200 blocks", ad, 200);
     run<true, 0>("train, dropout off (thr = 0), hidden stored", a, 256);
