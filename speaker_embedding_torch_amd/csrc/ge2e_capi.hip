@@ -705,7 +705,16 @@ struct SideCtx {
     SideCtx(ge2e_handle h_, hipStream_t m) : h(h_), main_st(m) {
         if (!h->overlap) return;
         { std::lock_guard<std::mutex> g(h->mu); if (h->prof_mask & GE2E_K_SERIAL) return; }   // measuring kernels alone
-        if (!h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return; }
+        if (!h->side) {
+            // GE2E_SIDE_PRIO=hi|lo (development): the weight-gradient stream at the device's greatest / least priority
+            const char* pr = std::getenv("GE2E_SIDE_PRIO");
+            int lo = 0, hi = 0;
+            hipError_t e;
+            if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
+                e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo);
+            else e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+            if (e != hipSuccess) { h->side = nullptr; return; }
+        }
         // this backward's own event set: one whose previous backward has completed on the device, else a new one
         std::lock_guard<std::mutex> g(h->mu);
         for (auto* s : h->event_sets)
@@ -908,7 +917,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm);
         a.emb = (float*)(ws + L.emb_keep); a.emb_out = out_emb;       // both copies from the one kernel (no device-to-device copy)
         auto kern = tail_fwd_kernel<T>;
-        GE2E_LAUNCH(h, kern, dim3(n / samples), dim3(256), 0, st, a);
+        GE2E_LAUNCH(h, kern, dim3((n / samples + TAIL_RB - 1) / TAIL_RB), dim3(256), 0, st, a);
     }
     return 0;
 }

@@ -223,38 +223,57 @@ struct TailArgs {
     float* dgf; float* dbf; float* dwq; float* dbq;
 };
 
-template <typename T>
-__global__ void __launch_bounds__(256) tail_fwd_kernel(const TailArgs p) {
-    __shared__ float red[4];
-    __shared__ float zs[256];
-    const int m = blockIdx.x, c = threadIdx.x;
-    float zsum = 0.0f;
-    for (int s = 0; s < p.samples; ++s) {
-        const int row = m * p.samples + s;
-        const float v = to_f32(((const T*)p.h)[(size_t)row * p.T * 256 + c]);
-        const float mean = block256_sum(v, red) * (1.0f / 256.0f);
-        const float d = v - mean;
-        const float rs = 1.0f / sqrtf(block256_sum(d * d, red) * (1.0f / 256.0f) + p.eps);
-        const float xh = d * rs;
-        if (p.xhat) { p.xhat[(size_t)row * 256 + c] = xh; if (c == 0) p.rstd[row] = rs; }
-        zsum += xh * p.gf[c] + p.bf[c];
-    }
-    const float z = zsum / (float)p.samples;
-    if (p.zm) p.zm[(size_t)m * 256 + c] = z;
-    zs[c] = z;
-    __syncthreads();
-    float e = p.bq[c];
-#pragma unroll 8
-    for (int k = 0; k < 256; ++k) e += zs[k] * p.wqT[k * 256 + c];
-    const float nn = fmaxf(sqrtf(block256_sum(e * e, red)), 1e-12f);
-    p.emb[(size_t)m * 256 + c] = e / nn;
-    if (p.emb_out) p.emb_out[(size_t)m * 256 + c] = e / nn;
-    if (c == 0 && p.nrm) p.nrm[m] = nn;
-}
-
 // TAIL_RB embeddings per block: the projection matrix is streamed from L2 once per block (32 loads in flight per
 // thread) and the LN_f gradient atomics shrink by the same factor.  grid = ceil(M / TAIL_RB), M = N / samples
 constexpr int TAIL_RB = 4;
+template <typename T>
+__global__ void __launch_bounds__(256) tail_fwd_kernel(const TailArgs p) {
+    __shared__ float red[4];
+    __shared__ float zs[TAIL_RB][256];
+    const int c = threadIdx.x, M = p.N / p.samples;
+    const int mb = blockIdx.x * TAIL_RB;
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) {
+        const int m = mb + u;
+        float z = 0.0f;
+        if (m < M) {                                   // block-uniform
+            float zsum = 0.0f;
+            for (int s = 0; s < p.samples; ++s) {
+                const int row = m * p.samples + s;
+                const float v = to_f32(((const T*)p.h)[(size_t)row * p.T * 256 + c]);
+                const float mean = block256_sum(v, red) * (1.0f / 256.0f);
+                const float d = v - mean;
+                const float rs = 1.0f / sqrtf(block256_sum(d * d, red) * (1.0f / 256.0f) + p.eps);
+                const float xh = d * rs;
+                if (p.xhat) { p.xhat[(size_t)row * 256 + c] = xh; if (c == 0) p.rstd[row] = rs; }
+                zsum += xh * p.gf[c] + p.bf[c];
+            }
+            z = zsum / (float)p.samples;
+            if (p.zm) p.zm[(size_t)m * 256 + c] = z;
+        }
+        zs[u][c] = z;
+    }
+    __syncthreads();
+    float e[TAIL_RB];
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) e[u] = p.bq[c];
+#pragma unroll 16
+    for (int k = 0; k < 256; ++k) {
+        const float w = p.wqT[k * 256 + c];
+#pragma unroll
+        for (int u = 0; u < TAIL_RB; ++u) e[u] += zs[u][k] * w;
+    }
+#pragma unroll
+    for (int u = 0; u < TAIL_RB; ++u) {
+        const int m = mb + u;
+        if (m >= M) break;                             // block-uniform
+        const float nn = fmaxf(sqrtf(block256_sum(e[u] * e[u], red)), 1e-12f);
+        p.emb[(size_t)m * 256 + c] = e[u] / nn;
+        if (p.emb_out) p.emb_out[(size_t)m * 256 + c] = e[u] / nn;
+        if (c == 0 && p.nrm) p.nrm[m] = nn;
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) tail_bwd_kernel(const TailArgs p) {
     __shared__ float red[4];
@@ -399,14 +418,24 @@ __global__ void __launch_bounds__(256) loss_reduce_kernel(const LossArgs p) {
 // dC_y[s][c] = w ((sum_i G0[i][s] ehat_i[c]) / cn_s - (sum_i G0[i][s] cos[i][s]) c_s[c] / cn_s^2) over slice y of the utterances: the expression
 // is linear in the two sums, so the row kernel adds the Y slabs.  grid = (S, Y)
 __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p) {
+    __shared__ float gq[256], gcq[256];     // this slice's G0[q][s] / en_q and G0[q][s] cos[q][s] (the row loop then carries ONE load per iteration)
     const int s = blockIdx.x, c = threadIdx.x;
     const int per = (p.N + gridDim.y - 1) / gridDim.y, q0 = blockIdx.y * per, q1 = min(p.N, q0 + per);
     float a = 0.0f, gc = 0.0f;
-#pragma unroll 4
-    for (int q = q0; q < q1; ++q) {
-        const float g = p.G[(size_t)q * p.S + s];
-        a += g * p.emb[(size_t)q * 256 + c] / p.en[q];
-        gc += g * p.cosm[(size_t)q * p.S + s];
+    for (int qb = q0; qb < q1; qb += 256) {
+        const int nq = min(256, q1 - qb);
+        __syncthreads();
+        if (c < nq) {
+            const float g = p.G[(size_t)(qb + c) * p.S + s];
+            gq[c] = g / p.en[qb + c];
+            gcq[c] = g * p.cosm[(size_t)(qb + c) * p.S + s];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < nq; ++q) {
+            a += gq[q] * p.emb[(size_t)(qb + q) * 256 + c];
+            gc += gcq[q];
+        }
     }
     const float cn = p.cn[s];
     p.dC[((size_t)blockIdx.y * p.S + s) * 256 + c] = p.w * (a / cn - gc * p.cent[(size_t)s * 256 + c] / (cn * cn));
@@ -414,13 +443,23 @@ __global__ void __launch_bounds__(256) loss_bwd_centroid_kernel(const LossArgs p
 
 // d_emb_i = gscale * ( w (G0_i chat)/en_i - w (G0_i . cos_i) e_i / en_i^2 + dC[spk(i)] / P );   dL/dw += gscale G0_i . cos_i,  dL/db -= gscale sum_s G0[i][s]
 __global__ void __launch_bounds__(256) loss_bwd_row_kernel(const LossArgs p) {
+    __shared__ float gn[256], gcs[256], gss[256];   // per speaker: G0[i][s] / cn_s, G0[i][s] cos[i][s], G0[i][s]
     const int irow = blockIdx.x, c = threadIdx.x;
     float a = 0.0f, gc = 0.0f, gs = 0.0f;
-    for (int s = 0; s < p.S; ++s) {
-        const float g = p.G[(size_t)irow * p.S + s];
-        a += g * p.cent[(size_t)s * 256 + c] / p.cn[s];
-        gc += g * p.cosm[(size_t)irow * p.S + s];
-        gs += g;
+    for (int sb = 0; sb < p.S; sb += 256) {
+        const int ns = min(256, p.S - sb);
+        __syncthreads();
+        if (c < ns) {
+            const float g = p.G[(size_t)irow * p.S + sb + c];
+            gn[c] = g / p.cn[sb + c]; gcs[c] = g * p.cosm[(size_t)irow * p.S + sb + c]; gss[c] = g;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int s = 0; s < ns; ++s) {
+            a += gn[s] * p.cent[(size_t)(sb + s) * 256 + c];
+            gc += gcs[s];
+            gs += gss[s];
+        }
     }
     float dc = 0.0f;
     for (int y = 0; y < p.Y; ++y) dc += p.dC[((size_t)y * p.S + irow / p.P) * 256 + c];
