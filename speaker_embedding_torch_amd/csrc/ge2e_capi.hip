@@ -508,7 +508,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             // (measured alone -- GE2E_K_SERIAL / GE2E_NO_OVERLAP: nothing to share the chip with -- a launch takes every CU)
             bool alone = !h->overlap;
             { std::lock_guard<std::mutex> g(h->mu); alone = alone || (h->prof_mask & GE2E_K_SERIAL) != 0; }
-            int splits = std::min(alone ? WK_MAX_BLOCKS : std::min(WK_MAX_BLOCKS, blocks_cap), h->num_cus) / ntile;
+            int splits = std::min(alone ? WK_MAX_BLOCKS : std::min(WK_MAX_BLOCKS, a.blocks > 0 ? a.blocks : blocks_cap), h->num_cus) / ntile;
             // whole XCD rounds: the kernel deals row slices to the 8 XCDs (wgrad_ks.cuh), so a multiple of 8 leaves no XCD a block short
             if (splits >= 8) splits = std::min((splits + 4) / 8 * 8, WK_MAX_BLOCKS / ntile / 8 * 8);
             splits = std::max(1, std::min(splits, stages / 8));          // at least 8 stages per block
@@ -959,6 +959,13 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     // last side-stream reader of each buffer set (Layout: layer l uses set l % nset, dQKV l % nqkv); null = nobody to wait for
     hipEvent_t g_set1[2] = {nullptr, nullptr}, g_set2[2] = {nullptr, nullptr}, g_dF[2] = {nullptr, nullptr}, g_dQKV[3] = {nullptr, nullptr, nullptr};
     hipEvent_t g_dH[3] = {nullptr, nullptr, nullptr};    // last weight-gradient-stream reader of dHx[i] (the norm2 column sums)
+    // The norm2 column sums read buffers that a <= 3-layer stack never reuses (dHx rotates over three), so they can run at ANY later time: they
+    // go to the END of the main chain, which otherwise idles ~170 us while the weight-gradient stream finishes (step 3.569 -> 3.541 ms;
+    // GE2E_NO_COLSUM_END=1 keeps them on the weight-gradient stream, as deeper stacks and runs with bucket callbacks -- whose layer buckets
+    // would have to be split -- do anyway)
+    static const bool colsum_end = getenv("GE2E_NO_COLSUM_END") == nullptr;
+    const bool defer_colsum = colsum_end && !cb && c.layers <= 3 && std::getenv("GE2E_DEBUG_BWD_STOP") == nullptr;   // (a stopped backward never reaches its end)
+    LnBwdArgs deferred[8]; int ndeferred = 0;
     {
         TailArgs a{};
         a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
@@ -992,15 +999,21 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             else return ll >= 0 && ll < c.layers - 1 && L.fbits[ll] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && maskbits_on() && ffn_chain_bwd_on();
         };
         const bool chain_bwd = uses_chain_bwd(l);
+        // The main chain ends ~170 us before the weight-gradient stream (profiles/r03_step_timeline.txt): the products of the layer that is
+        // processed LAST take a larger share of the chip.  GE2E_WGRAD_KS_BLOCKS_L0 = blocks, GE2E_WGRAD_KS_L0_FROM = first product (0-3) it applies to.
+        static const int l0_blocks = [] { const char* e = getenv("GE2E_WGRAD_KS_BLOCKS_L0"); return e ? atoi(e) : 0; }();
+        static const int l0_from = [] { const char* e = getenv("GE2E_WGRAD_KS_L0_FROM"); return e ? atoi(e) : 0; }();
+        auto wk_blocks = [&](int product) { return l == 0 && l0_blocks > 0 && product >= l0_from ? l0_blocks : 0; };
         // after this layer's last dgrad GEMM: the norm2 column sums of the layer below, on the weight-gradient stream (they read its dL/d(output))
         bool forked_after_dh = false;
         auto colsum_below = [&](bool already_forked = false) -> int {
             if (!uses_chain_bwd(l - 1)) return 0;
-            if (!already_forked) sc.fork();              // (armed on the dgrad GEMM that wrote b_dHin)
-            forked_after_dh = true;
             LnBwdArgs a{};
             a.dy = b_dHin; a.y = ws + L.h2[l - 1]; a.gamma = P[lp(l - 1, L_N2_W)]; a.beta = P[lp(l - 1, L_N2_B)];
             a.dgamma = G(lp(l - 1, L_N2_W)); a.dbeta = G(lp(l - 1, L_N2_B)); a.R = R;
+            if (defer_colsum) { deferred[ndeferred++] = a; return 0; }
+            if (!already_forked) sc.fork();              // (armed on the dgrad GEMM that wrote b_dHin)
+            forked_after_dh = true;
             auto kern = ln_colsum_kernel<T>;
             GE2E_LAUNCH(h, kern, dim3(std::min(512, (R + 31) / 32)), dim3(256), 0, wst, a);
             g_dH[l % L.nH] = sc.mark();                  // b_dHin = dHx[l % nH]
@@ -1063,14 +1076,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         {   // (started right after norm2's backward instead, next to the dF GEMM that streams the same gm and f: no gain, 4.10 vs 4.10 ms)
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
-            a.R = Rl; a.N = d; a.K = c.ffn;
+            a.R = Rl; a.N = d; a.K = c.ffn; a.blocks = wk_blocks(0);
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_set1[bs] = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
-            a.R = Rl; a.N = c.ffn; a.K = d;
+            a.R = Rl; a.N = c.ffn; a.K = d; a.blocks = wk_blocks(1);
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_dF[bs] = sc.mark();
         }
@@ -1110,7 +1123,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
-            a.R = Rl; a.N = d; a.K = d;
+            a.R = Rl; a.N = d; a.K = d; a.blocks = wk_blocks(2);
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
             if (!last) g_set2[bs] = sc.mark();
         }
@@ -1126,7 +1139,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             sc.fork();
             WgradArgs w{};
             w.Y = b_dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
-            w.R = R; w.N = 3 * d; w.K = d;
+            w.R = R; w.N = 3 * d; w.K = d; w.blocks = wk_blocks(3);
             CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart, &pend)));
             CK(flush_wk_reduce(h, wst, pend));
             g_dQKV[bq] = sc.mark();
@@ -1134,7 +1147,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             g.A = b_dQKV; g.lda = 3 * d; g.W = ws + L.w_inT[l]; g.ldw = 3 * d; g.C = b_dHin; g.ldc = d;
             g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP2; g.ldr = d;
             sc.wait(g_dH[l % L.nH]);
-            if (uses_chain_bwd(l - 1)) sc.arm();
+            if (uses_chain_bwd(l - 1) && !defer_colsum) sc.arm();
             CK((gemm128<T, EPI_ADD>(h, st, g)));
             CK(colsum_below());
         } else {
@@ -1205,6 +1218,10 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));                 // (no split-K scratch here: wpart belongs to the side stream)
         }
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
+        for (int q = 0; q < ndeferred; ++q) {
+            auto kern = ln_colsum_kernel<T>;
+            GE2E_LAUNCH(h, kern, dim3(std::min(512, (R + 31) / 32)), dim3(256), 0, st, deferred[q]);
+        }
     }
     return 0;                                             // backward_impl joins the side stream: the caller's stream owns every gradient again
 }

@@ -305,6 +305,7 @@ struct WgradArgs {
     int rows_per_split;         // multiple of the stage height
     int tiles_n, tiles_k;       // 128x128 output tiles along N and K
     int T, mel;
+    int blocks;                 // host side: wgrad_ks blocks for this product (0 = the library's default share of the chip)
 };
 
 template <typename T, int XLOAD, int NS_ = 3, int KGS = 2>
