@@ -22,6 +22,7 @@
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
+#include "gemm_sk.cuh"
 #include "ffn.cuh"
 #include "wgrad_ks.cuh"
 #include "misc.cuh"
@@ -113,6 +114,7 @@ struct Layout {
     size_t pbits = 0;            // [R][32] sign bits of the prenet's pre-activation (train: written by its forward epilogue, read by prenet_bwd_kernel)
     size_t qkv[MAX_LAYERS], o[MAX_LAYERS], h1[MAX_LAYERS], rstd1[MAX_LAYERS], f[MAX_LAYERS], h2[MAX_LAYERS], rstd2[MAX_LAYERS];
     size_t lse[MAX_LAYERS];      // [R, heads] fp32 log-sum-exp of the attention scores (train only)
+    size_t skpart;               // 16-bit modes: [SK_KS][n][256] fp32 partial tiles of the last layer's split-K products (gemm_sk.cuh), or -1
     size_t fbits[MAX_LAYERS];    // [R, ffn / 8] bytes: "stored FFN hidden > 0", one bit per element (train, 16-bit modes, full layers;
                                  // written by the chained FFN kernel, read by the backward's dF GEMM instead of the hidden itself)
     size_t adelta = 0;           // [R, heads] fp32 dO . O of the layer in backward (long-sequence attention only)
@@ -188,6 +190,7 @@ Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_m
         L.f[last] = take((size_t)n * f * e); L.h2[last] = take((size_t)n * d * e);
         L.rstd1[last] = L.rstd2[last] = (size_t)-1;
     }
+    L.skpart = e == 2 && n <= SK_MAX_M ? take((size_t)SK_KS * n * 256 * 4) : (size_t)-1;
     L.lq0 = take((size_t)n * d * e);
     if (train) {
         L.lqk = take((size_t)n * 4 * d * 4); L.lprob = take((size_t)n * 4 * (size_t)t * 4); L.lctx = take((size_t)n * 4 * d * 4);
@@ -371,6 +374,29 @@ int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     // 179 -> 144 us for FFN1; the other epilogues measure the same either way and keep the one-barrier double buffer
     constexpr int NBUF = (EPI == EPI_BIAS_RELU_DROP) ? 1 : 2;
     return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD, NBUF>(h, st, a);
+}
+// K = 1024 products on the last layer's compact rows: split-K over 64-row pieces + a reduce / epilogue launch (gemm_sk.cuh).  part: [SK_KS][M][256] fp32.
+inline bool gemm_sk_on() { static const bool off = getenv("GE2E_NO_SK_GEMM") != nullptr; return !off; }
+template <typename T, bool LN>
+int launch_gemm_sk(ge2e_handle h, hipStream_t st, const GemmArgs& a, float* part) {
+    if constexpr (sizeof(T) == 2) {
+        GemmSkArgs k{};
+        k.A = a.A; k.lda = a.lda; k.W = a.W; k.ldw = a.ldw; k.part = part; k.M = a.M; k.K = a.K; k.KS = SK_KS;
+        ProfScope ps(h, st, LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, 2.0 * ((double)a.M * a.K + (double)a.N * a.K + 2.0 * (double)a.M * a.N));
+        auto kern = gemm_sk_kernel<T>;
+        GE2E_LAUNCH(h, kern, dim3((a.M + 63) / 64, SK_KS), dim3(256), 0, st, k);
+        SkEpiArgs e{};
+        e.part = part; e.M = a.M; e.KS = SK_KS; e.bias = a.bias; e.R = a.R; e.ldr = a.ldr; e.C = a.C; e.ldc = a.ldc;
+        e.gamma = a.gamma; e.beta = a.beta; e.rstd = a.rstd; e.eps = a.eps; e.drop = a.drop; e.drow_mul = a.drow_mul;
+        auto epi = gemm_sk_epi_kernel<T, LN>;
+        GE2E_LAUNCH(h, epi, dim3((a.M + 3) / 4), dim3(256), 0, st, e);
+        return 0;
+    } else return fail(h, GE2E_EUNSUPPORTED, "gemm_sk: 16-bit storage modes only");
+}
+template <typename T>
+bool gemm_sk_shape(const GemmArgs& a, size_t skpart) {
+    return sizeof(T) == 2 && gemm_sk_on() && skpart != (size_t)-1 && a.N == 256 && a.K % (32 * SK_KS) == 0 && a.K >= 512 && a.M > 0 && a.M <= SK_MAX_M &&
+           a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0;
 }
 template <typename T>
 int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
@@ -905,7 +931,8 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.gamma = P[lp(l, L_N2_W)]; a.beta = P[lp(l, L_N2_B)]; a.eps = c.ln_eps;
             a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_ff(l)); a.drow_mul = rmul;
-            CK(gemm_ln<T>(h, st, a));
+            if (last && gemm_sk_shape<T>(a, L.skpart)) CK((launch_gemm_sk<T, true>(h, st, a, (float*)(ws + L.skpart))));
+            else CK(gemm_ln<T>(h, st, a));
         }
     }
     {   // final LN at t = 0 -> slice mean -> projection -> L2 normalise
@@ -1091,7 +1118,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             GemmArgs a{};
             a.A = b_dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = b_dHb; a.ldc = d;
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
-            CK((gemm128<T, EPI_ADD>(h, st, a)));
+            if (last && gemm_sk_shape<T>(a, L.skpart)) CK((launch_gemm_sk<T, false>(h, st, a, (float*)(ws + L.skpart))));
+            else CK((gemm128<T, EPI_ADD>(h, st, a)));
         }
         if (!last) sc.wait(g_set2[bs]);
         gm = d_sa.thr ? b_dM2 : b_dP2;
