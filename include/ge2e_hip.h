@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GE2E_ABI_VERSION 3
+#define GE2E_ABI_VERSION 4
 
 enum {
     GE2E_OK = 0,
@@ -102,7 +102,11 @@ int ge2e_encoder_forward_mel16(ge2e_handle h, void* stream, const void* mel_f16,
 /* Must follow a train-mode forward on the SAME workspace, inputs, seed and step.
  * mel:        the forward's input pointer (either dtype; not read again: the packed rows live in the workspace)
  * d_emb:      device fp32 [n_utts / samples, emb]
- * grads_flat: device fp32 [ge2e_param_total()], OVERWRITTEN with dL/dparam at ge2e_param_offset(i) */
+ * grads_flat: device fp32 [ge2e_param_total()], OVERWRITTEN with dL/dparam at ge2e_param_offset(i); any 4-byte-aligned address
+ *             (an offset view of a larger buffer is fine).
+ * Reproducibility: the forward is bitwise reproducible; the parameter gradients are reproducible to fp32 SUMMATION ORDER only
+ * (bias gradients, the small-shape weight-gradient kernel and the split-K reduce pass add partial sums with float atomics:
+ * two runs of one step agree to ~1e-6 relative, not bit for bit). */
 int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
                           const float* const* params, const float* d_emb, float* grads_flat,
                           void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step);
@@ -116,7 +120,7 @@ int ge2e_encoder_backward(ge2e_handle h, void* stream, const float* mel, int n_u
  * backward chain on `stream` is not held up by the hand-off. */
 typedef void (*ge2e_bucket_cb)(void* user, int64_t element_offset, int64_t element_count);
 /* The stream behind which a bucket reported by ge2e_encoder_backward_cb(…, stream, …) is final: the internal
- * weight-gradient stream, or `stream` itself when the overlap is off (GE2E_NO_OVERLAP).  Valid inside the callback. */
+ * weight-gradient stream, or `stream` itself when the overlap is off (option "no_overlap").  Valid inside the callback. */
 void* ge2e_bucket_stream(ge2e_handle h, void* stream);
 int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int n_utts, int frames, int samples,
                              const float* const* params, const float* d_emb, float* grads_flat,
@@ -198,6 +202,18 @@ int ge2e_profile_read(ge2e_handle h, int klass, double* total_ms, double* total_
  * Used by the parity tests to localise a failing kernel; returns GE2E_EINVAL for unknown names. */
 int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int train,
                    size_t* offset_bytes, size_t* size_bytes);
+
+/* Development / diagnostic options.  The library never reads the process environment; the defaults are the shipped configuration.
+ * An option is process-wide and takes effect at the next call that depends on it ("no_overlap": at the next ge2e_create).  Names
+ * (ge2e_option_name(0 .. ) enumerates them, NULL past the end): kernel-selection ablations "no_overlap", "no_ws_gemm", "no_kl_gemm",
+ * "no_lnfuse", "no_sk_gemm", "no_ffn_chain", "ffn_wv" (4 | 8), "no_ffn_chain_bwd", "no_wgrad_ks", "no_reduce_batch",
+ * "wgrad_ks_blocks" (n), "no_event_bind", "no_maskbits", "no_colsum_end", "no_prenet_fuse", "no_attn_bwd1"; test hooks
+ * "debug_bwd_stop" (k >= 0: a backward returns after k layers so that ge2e_debug_tap shows that layer's scratch; -1 off) and
+ * "debug_side_delay_us" (hold the weight-gradient stream back after every fork).  Unknown name: GE2E_EINVAL.
+ * (The ctypes loader forwards GE2E_<NAME>=value environment variables to this call only when GE2E_DEV_SWITCHES=1 is set.) */
+int ge2e_set_option(const char* name, int value);
+int ge2e_get_option(const char* name, int* value);
+const char* ge2e_option_name(int index);
 
 /* Host-side helpers shared with the CPU oracle (dropout stream definition; no GPU needed). */
 uint32_t ge2e_drop_key(uint64_t seed, uint64_t step, int site);

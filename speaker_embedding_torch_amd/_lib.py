@@ -14,7 +14,7 @@ BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
 PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
-ABI_VERSION = 3
+ABI_VERSION = 4
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD, K_FFN = 1, 2, 4, 8, 16, 32, 64
 FWD_PREPARED = 2       # ge2e_encoder_forward's `train` argument: eval forward, weight copies already in the workspace
 K_SERIAL = 1 << 30      # with a class bit: the backward keeps its weight gradients on the caller's stream (kernels timed alone)
@@ -75,10 +75,49 @@ _SIG = {
                                     C.POINTER(C.c_int64)]),
     "ge2e_debug_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int,
                                  C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ge2e_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "ge2e_get_option": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    "ge2e_option_name": (C.c_char_p, [C.c_int]),
     "ge2e_drop_key": (C.c_uint32, [C.c_uint64, C.c_uint64, C.c_int]),
     "ge2e_drop_keep": (C.c_int, [C.c_uint32, C.c_uint32, C.c_float]),
 }
 SYMBOLS = tuple(_SIG)
+
+
+def option_names(lib=None):
+    lib = lib or load()
+    out, i = [], 0
+    while True:
+        n = lib.ge2e_option_name(i)
+        if n is None:
+            return out
+        out.append(n.decode())
+        i += 1
+
+
+def set_option(name, value):
+    """Development / diagnostic options of the library (include/ge2e_hip.h, ge2e_set_option); process-wide."""
+    if load().ge2e_set_option(name.encode(), int(value)) != 0:
+        raise KeyError(name)
+
+
+def get_option(name):
+    v = C.c_int()
+    if load().ge2e_get_option(name.encode(), C.byref(v)) != 0:
+        raise KeyError(name)
+    return v.value
+
+
+def _dev_switches(lib):
+    """GE2E_DEV_SWITCHES=1 (tools/ab.sh, tools/switch_test.sh, the scheduling tests): GE2E_<NAME>=value -> ge2e_set_option(name, value).
+    Without it the environment has no influence on the library: the product's kernel selection is the compiled-in default."""
+    for name in option_names(lib):
+        v = os.environ.get("GE2E_" + name.upper())
+        if v is not None:
+            try:
+                lib.ge2e_set_option(name.encode(), int(v))
+            except ValueError:
+                raise RuntimeError(f"GE2E_{name.upper()}={v!r}: integer expected")
 
 
 def load():
@@ -86,6 +125,19 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
+            dev = os.environ.get("GE2E_DEV_SWITCHES") == "1"
+            # a same-box A/B of two BUILDS (tools/ab_lib.sh) loads its variants from tools/abl/ and leaves the in-tree library alone
+            override = os.environ.get("GE2E_LIB_OVERRIDE") if dev else None
+            if override:
+                lib = C.CDLL(override)
+                for name, (res, args) in _SIG.items():
+                    fn = getattr(lib, name)
+                    fn.restype, fn.argtypes = res, args
+                import sys
+                print(f"[ge2e] development build loaded from {override} (hash {lib.ge2e_source_hash().decode()})", file=sys.stderr)
+                _dev_switches(lib)
+                _lib = lib
+                return _lib
             if not os.path.exists(LIB):
                 raise RuntimeError(
                     f"{LIB} is missing: the GE2E HIP extension has not been built "
@@ -101,6 +153,8 @@ def load():
                 raise RuntimeError(
                     f"{LIB} is stale: it was compiled from sources with hash {built}, csrc/ now hashes to {want} "
                     "(run `python -m speaker_embedding_torch_amd._build`)")
+            if dev:
+                _dev_switches(lib)
             _lib = lib
     return _lib
 

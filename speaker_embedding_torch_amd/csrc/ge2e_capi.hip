@@ -40,6 +40,39 @@ constexpr int MAX_FRAMES = 1024;          // longer sequences stream through the
 
 struct ParamInfo { std::string name; int64_t numel, offset; };
 
+// Development / diagnostic options (ge2e_set_option).  The library never reads the process environment: the defaults below ARE the
+// shipped configuration, an option is process-wide and is read at every call that depends on it (nothing is latched on first use).
+// The ctypes loader forwards GE2E_<NAME> environment variables here only when GE2E_DEV_SWITCHES=1 (tools/ab.sh, tools/switch_test.sh).
+enum Opt {
+    O_NO_OVERLAP, O_NO_WS_GEMM, O_NO_KL_GEMM, O_NO_LNFUSE, O_NO_SK_GEMM, O_NO_FFN_CHAIN, O_FFN_WV, O_NO_FFN_CHAIN_BWD, O_NO_WGRAD_KS,
+    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE, O_NO_ATTN_BWD1,
+    O_DEBUG_BWD_STOP, O_DEBUG_SIDE_DELAY_US, O_COUNT
+};
+struct OptDef { const char* name; int def; };
+constexpr OptDef OPT_DEFS[O_COUNT] = {
+    {"no_overlap", 0},          // weight gradients on the caller's stream (no side stream); read by ge2e_create
+    {"no_ws_gemm", 0},          // tiled kernel instead of the weight-stationary K = 256 GEMM
+    {"no_kl_gemm", 0},          // tiled kernel instead of the stage-stream K = 1024 GEMM
+    {"no_lnfuse", 0},           // norm1 backward as its own launch
+    {"no_sk_gemm", 0},          // the last layer's K = 1024 products on the stage-stream / tiled kernels
+    {"no_ffn_chain", 0},        // FFN as two GEMM launches
+    {"ffn_wv", 0},              // 4 / 8: force one block shape of the chained FFN forward
+    {"no_ffn_chain_bwd", 0},    // norm2 backward, dF, dH1 as three launches
+    {"no_wgrad_ks", 0},         // 128 x 128 atomic weight-gradient kernel instead of wgrad_ks
+    {"no_reduce_batch", 0},     // one reduce pass per weight-gradient product instead of one per layer
+    {"wgrad_ks_blocks", 0},     // blocks per wgrad_ks launch (0: WK_DEFAULT_BLOCKS)
+    {"no_event_bind", 0},       // fences recorded as separate markers
+    {"no_maskbits", 0},         // dF reads the stored hidden as its mask
+    {"no_colsum_end", 0},       // norm2 column sums on the weight-gradient stream
+    {"no_prenet_fuse", 0},      // prenet backward as recompute GEMM + weight-gradient launch
+    {"no_attn_bwd1", 0},        // attention backward as the two-phase kernel (every score evaluated twice) instead of the single-evaluation kernel
+    {"debug_bwd_stop", -1},     // >= 0: backward returns after k layers (parity tests read that layer's scratch through ge2e_debug_tap)
+    {"debug_side_delay_us", 0}, // tests: hold the weight-gradient stream back after every fork
+};
+std::atomic<int> g_opt[O_COUNT];
+struct OptInit { OptInit() { for (int i = 0; i < O_COUNT; ++i) g_opt[i].store(OPT_DEFS[i].def, std::memory_order_relaxed); } } g_opt_init;
+inline int opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
+
 }  // namespace
 
 struct ProfRec { int klass; hipEvent_t start, stop; double work, bytes; int counts; };
@@ -280,10 +313,7 @@ __global__ void debug_delay_kernel(unsigned ticks) {
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(64);
 }
-inline int debug_side_delay_us() {
-    static const int us = [] { const char* e = getenv("GE2E_DEBUG_SIDE_DELAY_US"); const int v = e ? atoi(e) : 0; return std::max(0, std::min(v, 5000)); }();
-    return us;
-}
+inline int debug_side_delay_us() { return std::max(0, std::min(opt(O_DEBUG_SIDE_DELAY_US), 5000)); }
 #define GE2E_LAUNCH(h, kern, grid, block, smem, st, ...)                                                   \
     do {                                                                                                    \
         static std::atomic<size_t> attr_max{(size_t)48 * 1024};                                             \
@@ -328,8 +358,7 @@ constexpr bool ws_epilogue() {
     return sizeof(T) == 2 && (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_MASK || EPI == EPI_LN);
 }
 inline bool ws_shape(const GemmArgs& a) {
-    static const bool off = getenv("GE2E_NO_WS_GEMM") != nullptr;
-    return !off && a.K == 256 && a.N % 256 == 0 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0;
+    return !opt(O_NO_WS_GEMM) && a.K == 256 && a.N % 256 == 0 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0;
 }
 template <typename T, int EPI>
 int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
@@ -351,7 +380,7 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 
 // LayerNorm backward + the K = 256 GEMM that consumes it, one launch (gemm_ws_lnbwd_kernel).  a.A = dy, a.gamma / beta /
 // rstd / drop / drow_mul describe the LayerNorm and the dropout in front of the sub-layer, f the rest.
-inline bool lnfuse_on() { static const bool off = getenv("GE2E_NO_LNFUSE") != nullptr; return !off; }
+inline bool lnfuse_on() { return !opt(O_NO_LNFUSE); }
 template <typename T, int EPI>
 int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const LnFuseArgs& f) {
     const int cg = a.N / 256, ntiles = (a.M + 15) / 16;
@@ -376,7 +405,7 @@ int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD, NBUF>(h, st, a);
 }
 // K = 1024 products on the last layer's compact rows: split-K over 64-row pieces + a reduce / epilogue launch (gemm_sk.cuh).  part: [SK_KS][M][256] fp32.
-inline bool gemm_sk_on() { static const bool off = getenv("GE2E_NO_SK_GEMM") != nullptr; return !off; }
+inline bool gemm_sk_on() { return !opt(O_NO_SK_GEMM); }
 template <typename T, bool LN>
 int launch_gemm_sk(ge2e_handle h, hipStream_t st, const GemmArgs& a, float* part) {
     if constexpr (sizeof(T) == 2) {
@@ -404,8 +433,7 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
         if (ws_shape(a)) return launch_gemm_ws<T, EPI_LN>(h, st, a);
         // FFN2 + LayerNorm (K = 1024): persistent stage-stream kernel, one 512-thread block per CU (gemm_kl.cuh).  It needs a
         // whole CU's LDS, so it is used where nothing shares the machine (the forward chain), not beside the weight gradients.
-        static const bool kl_off = getenv("GE2E_NO_KL_GEMM") != nullptr;
-        if (!kl_off && a.K == 1024 && a.N == 256 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && a.ldr % 8 == 0) {
+        if (!opt(O_NO_KL_GEMM) && a.K == 1024 && a.N == 256 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && a.ldr % 8 == 0) {
             const int ntiles = (a.M + 127) / 128;
             if (h->num_cus <= 0) {
                 int dev = h->device >= 0 ? h->device : 0, n = 0;
@@ -425,7 +453,7 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 
 // FFN1 -> ReLU -> dropout -> FFN2 -> dropout -> residual -> LayerNorm in one launch (ffn.cuh): 16-bit modes, full-height layers.
 // The choice never depends on M (a row's result must not depend on the batch it sits in): every non-last layer takes it.
-inline bool ffn_chain_on() { static const bool off = getenv("GE2E_NO_FFN_CHAIN") != nullptr; return !off; }
+inline bool ffn_chain_on() { return !opt(O_NO_FFN_CHAIN); }
 template <typename T>
 int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
     if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "ffn chain: 16-bit modes only");
@@ -440,7 +468,7 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         // 256 CUs take three rounds with a quarter of the chip idle, where 1200 half-size passes on 512 half-CU slots flow
         // (measured alone: eval 160 vs 195 us, train 224 vs 238 us; 768,000 rows, 3000 passes: 826 vs 804 us).  Take the 8-wave
         // shape when its rounds are full enough to keep its per-CU advantage.  GE2E_FFN_WV = 4 / 8 forces one.
-        static const int wv_env = getenv("GE2E_FFN_WV") ? atoi(getenv("GE2E_FFN_WV")) : 0;
+        const int wv_env = opt(O_FFN_WV);
         const int np8 = (a.M + 255) / 256, rounds8 = (np8 + h->num_cus - 1) / h->num_cus;
         const double fill8 = (double)np8 / ((double)rounds8 * h->num_cus);
         const int wv = wv_env == 4 || wv_env == 8 ? wv_env : (fill8 >= (a.Fo ? 0.84 : 0.95) ? 8 : 4);
@@ -489,11 +517,11 @@ int launch_ffn_chain_bwd(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         return 0;
     }
 }
-inline bool ffn_chain_bwd_on() { static const bool off = getenv("GE2E_NO_FFN_CHAIN_BWD") != nullptr; return !off; }
+inline bool ffn_chain_bwd_on() { return !opt(O_NO_FFN_CHAIN_BWD); }
 
 // 256 x 256-tile split-K weight gradient (wgrad_ks.cuh) for the wide 16-bit products; everything else (and the rows beyond the
 // last multiple of 32) on the 128 x 128 kernel below.
-inline bool wgrad_ks_on() { static const bool off = getenv("GE2E_NO_WGRAD_KS") != nullptr; return !off; }
+inline bool wgrad_ks_on() { return !opt(O_NO_WGRAD_KS); }
 template <typename T, int XLOAD> int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a);
 
 // reduce passes of the split-K products launched since the last flush (one slab each): flushed as ONE launch at the end of a layer
@@ -503,7 +531,7 @@ struct WkPending {
     size_t slab_floats = 0;              // Layout::wslab
     float* slab(float* base) const { return base + (size_t)args.njobs * slab_floats; }
 };
-inline bool wk_batch_on() { static const bool off = getenv("GE2E_NO_REDUCE_BATCH") != nullptr; return !off; }
+inline bool wk_batch_on() { return !opt(O_NO_REDUCE_BATCH); }
 int flush_wk_reduce(ge2e_handle h, hipStream_t st, WkPending& pend) {
     if (pend.args.njobs == 0) return 0;
     ProfScope ps(h, st, GE2E_K_WGRAD, 0.0, 0.0, /*counts=*/false);        // class time, not a launch of the class
@@ -529,7 +557,7 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             // A block fills a whole CU (128 KB of LDS, every vector register), so the launch is sized to leave CUs to the backward's
             // main chain on the other stream: the two then share the chip in SPACE instead of taking turns (measured, step time:
             // 256 blocks 4.29 ms, 192 4.19, 160 4.16, 128 4.20, 96 4.26).  GE2E_WGRAD_KS_BLOCKS overrides.
-            static const int blocks_cap = [] { const char* e = getenv("GE2E_WGRAD_KS_BLOCKS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : WK_DEFAULT_BLOCKS; }();
+            const int blocks_cap = opt(O_WGRAD_KS_BLOCKS) > 0 ? opt(O_WGRAD_KS_BLOCKS) : WK_DEFAULT_BLOCKS;
             const int ntile = tn * tk;
             // (measured alone -- GE2E_K_SERIAL / GE2E_NO_OVERLAP: nothing to share the chip with -- a launch takes every CU)
             bool alone = !h->overlap;
@@ -546,18 +574,11 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             WgradKsArgs k{};
             k.Y = a.Y; k.ldy = a.ldy; k.X = a.X; k.ldx = a.ldx; k.part = part; k.db = a.db; k.R32 = R32; k.rows_per_split = sps * 32;
             k.tiles_n = tn; k.tiles_k = tk; k.splits = splits;
-            static const bool flat = getenv("GE2E_WGRAD_KS_FLAT") != nullptr;
-            k.flat_order = flat ? 1 : 0;
             // one scope around the product AND its reduce pass: `roofline.kernel` names both, and the class time is then what rocprof
             // shows for the two rows together
             {
                 ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R32 * (double)a.N * a.K, (double)R32 * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
-                static const bool atomic = getenv("GE2E_WGRAD_KS_ATOMIC") != nullptr;
-                k.dW = a.dW; k.ldw = a.ldw;
-                if (atomic) {
-                    auto kern = wgrad_ks_kernel<T, true>;
-                    GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
-                } else {
+                {
                 auto kern = wgrad_ks_kernel<T>;
                 GE2E_LAUNCH(h, kern, dim3(8 * ntile * ((splits + 7) / 8)), dim3(512), wgrad_ks_smem(), st, k);
                 // split groups: ~256 reduce blocks whatever the tile count (a single-tile product used to sum its 160 partials in 64 blocks)
@@ -628,9 +649,8 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
         size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 && DROP ? (size_t)TP * (TP / 4) : 0);    // + keep bits: a byte per (4 keys, query)
         // Two blocks of >= 5 waves per CU are enough for this kernel (960 x 160 alone: 310 us at 2 blocks per CU, 318-329 at 3, 415 at 1), and the
         // third block only takes registers and LDS from whatever the weight-gradient stream has in flight: a launch that would fit three asks
-        // for a little more LDS than a third of the CU's (step 3.785 -> 3.742 ms).  GE2E_ATTN_BWD_3PERCU=1 restores the natural occupancy.
-        static const bool three = getenv("GE2E_ATTN_BWD_3PERCU") != nullptr;
-        if (!three && nw >= 5 && 3 * smem <= (size_t)160 * 1024) smem = (size_t)160 * 1024 / 3 + 1024;
+        // for a little more LDS than a third of the CU's (step 3.785 -> 3.742 ms).
+        if (nw >= 5 && 3 * smem <= (size_t)160 * 1024) smem = (size_t)160 * 1024 / 3 + 1024;
         // a scheduling barrier after every tile group (32 keys / queries): 112-120 registers, three blocks per CU fit; spaced wider the
         // compiler hoists fragment loads (130 registers at 5 groups; 247-256 + spills when a loop never meets a barrier)
         auto kern = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 2>;
@@ -732,14 +752,8 @@ struct SideCtx {
         if (!h->overlap) return;
         { std::lock_guard<std::mutex> g(h->mu); if (h->prof_mask & GE2E_K_SERIAL) return; }   // measuring kernels alone
         if (!h->side) {
-            // GE2E_SIDE_PRIO=hi|lo (development): the weight-gradient stream at the device's greatest / least priority
-            const char* pr = std::getenv("GE2E_SIDE_PRIO");
-            int lo = 0, hi = 0;
-            hipError_t e;
-            if (pr && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess)
-                e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo);
-            else e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
-            if (e != hipSuccess) { h->side = nullptr; return; }
+            // (default priority: highest / lowest measured 4.46 / 4.54 vs 4.44 ms per step in round 1, +-0.01 ms in round 3)
+            if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; return; }
         }
         // this backward's own event set: one whose previous backward has completed on the device, else a new one
         std::lock_guard<std::mutex> g(h->mu);
@@ -759,7 +773,7 @@ struct SideCtx {
             hipEvent_t e = nullptr;
             // device-side fences between two streams of ONE device: no system-scope release (the kernels' own agent-scope release /
             // acquire at dispatch boundaries orders the data)
-            static const unsigned flags = hipEventDisableTiming | (getenv("GE2E_EVENT_SYSFENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
+            constexpr unsigned flags = hipEventDisableTiming | (unsigned)hipEventDisableSystemFence;
             if (hipEventCreateWithFlags(&e, flags) != hipSuccess) { err = 1; return nullptr; }
             set->ev.push_back(e);
         }
@@ -772,7 +786,7 @@ struct SideCtx {
         if (!on || bind_off()) return;
         tl_armed = ArmedEvent{ev(), main_st, 0};
     }
-    static bool bind_off() { static const bool off = getenv("GE2E_NO_EVENT_BIND") != nullptr; return off; }
+    static bool bind_off() { return opt(O_NO_EVENT_BIND) != 0; }
     void fork() {                           // side waits for everything enqueued on main so far
         if (!on) return;
         const ArmedEvent a = tl_armed;
@@ -949,7 +963,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
     return 0;
 }
 
-inline bool maskbits_on() { static const bool off = getenv("GE2E_NO_MASKBITS") != nullptr; return !off; }
+inline bool maskbits_on() { return !opt(O_NO_MASKBITS); }
 template <typename T>
 int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
@@ -977,7 +991,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     auto bucket = [&](int first, int last) {   // parameters [first, last] are final: tell the caller
         if (cb) cb(user, h->params[first].offset, h->params[last].offset + h->params[last].numel - h->params[first].offset);
     };
-    if (((uintptr_t)grads & 15) != 0) return fail(h, GE2E_EINVAL, "grads_flat must be 16-byte aligned");
+    if (((uintptr_t)grads & 3) != 0) return fail(h, GE2E_EINVAL, "grads_flat must be 4-byte aligned");
     GE2E_LAUNCH(h, zero_f32_kernel, dim3(512), dim3(256), 0, st, grads, (size_t)h->total);
     hipStream_t wst = sc.wstream();                       // stream of the weight-gradient kernels
     float* const wpart = L.wpart != (size_t)-1 ? (float*)(ws + L.wpart) : nullptr;   // split-K partial tiles (used in stream order on wst)
@@ -988,10 +1002,10 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     hipEvent_t g_dH[3] = {nullptr, nullptr, nullptr};    // last weight-gradient-stream reader of dHx[i] (the norm2 column sums)
     // The norm2 column sums read buffers that a <= 3-layer stack never reuses (dHx rotates over three), so they can run at ANY later time: they
     // go to the END of the main chain, which otherwise idles ~170 us while the weight-gradient stream finishes (step 3.569 -> 3.541 ms;
-    // GE2E_NO_COLSUM_END=1 keeps them on the weight-gradient stream, as deeper stacks and runs with bucket callbacks -- whose layer buckets
+    // option no_colsum_end keeps them on the weight-gradient stream, as deeper stacks and runs with bucket callbacks -- whose layer buckets
     // would have to be split -- do anyway)
-    static const bool colsum_end = getenv("GE2E_NO_COLSUM_END") == nullptr;
-    const bool defer_colsum = colsum_end && !cb && c.layers <= 3 && std::getenv("GE2E_DEBUG_BWD_STOP") == nullptr;   // (a stopped backward never reaches its end)
+    const int stop_after = opt(O_DEBUG_BWD_STOP);        // diagnostics only: >= 0 returns after k layers so ge2e_debug_tap sees that layer's scratch
+    const bool defer_colsum = !opt(O_NO_COLSUM_END) && !cb && c.layers <= 3 && stop_after < 0;   // (a stopped backward never reaches its end)
     LnBwdArgs deferred[8]; int ndeferred = 0;
     {
         TailArgs a{};
@@ -1008,9 +1022,6 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, wst, a);
     }
     bool tail_bucket_pending = true;                      // reported after the first join with the side stream
-    // diagnostics only: GE2E_DEBUG_BWD_STOP=k returns after k layers so ge2e_debug_tap sees that layer's scratch
-    const char* dbg_stop = std::getenv("GE2E_DEBUG_BWD_STOP");
-    const int stop_after = dbg_stop ? std::atoi(dbg_stop) : -1;
     const size_t esz = L.esz;
     for (int l = c.layers - 1; l >= 0; --l) {
         if (stop_after >= 0 && c.layers - 1 - l >= stop_after) return 0;
@@ -1026,11 +1037,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             else return ll >= 0 && ll < c.layers - 1 && L.fbits[ll] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && maskbits_on() && ffn_chain_bwd_on();
         };
         const bool chain_bwd = uses_chain_bwd(l);
-        // The main chain ends ~170 us before the weight-gradient stream (profiles/r03_step_timeline.txt): the products of the layer that is
-        // processed LAST take a larger share of the chip.  GE2E_WGRAD_KS_BLOCKS_L0 = blocks, GE2E_WGRAD_KS_L0_FROM = first product (0-3) it applies to.
-        static const int l0_blocks = [] { const char* e = getenv("GE2E_WGRAD_KS_BLOCKS_L0"); return e ? atoi(e) : 0; }();
-        static const int l0_from = [] { const char* e = getenv("GE2E_WGRAD_KS_L0_FROM"); return e ? atoi(e) : 0; }();
-        auto wk_blocks = [&](int product) { return l == 0 && l0_blocks > 0 && product >= l0_from ? l0_blocks : 0; };
+        // (a larger wgrad_ks share for the products of the layer processed last -- 208 / 256 blocks -- was measured in round 3: no effect)
+        auto wk_blocks = [&](int) { return 0; };
         // after this layer's last dgrad GEMM: the norm2 column sums of the layer below, on the weight-gradient stream (they read its dL/d(output))
         bool forked_after_dh = false;
         auto colsum_below = [&](bool already_forked = false) -> int {
@@ -1213,7 +1221,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     {   // through the PE dropout, alpha * pe and the ReLU, and the prenet's weight / bias gradients, in one launch (prenet_bwd.cuh): the masked
         // gradient of the pre-activation is formed on the way into the weight-gradient kernel's LDS tiles and never stored.  It stays on the
         // MAIN stream: the side stream's own last job (layer 0's in_proj gradient) ends later than this does.
-        static const bool unfused = getenv("GE2E_NO_PRENET_FUSE") != nullptr;
+        const bool unfused = opt(O_NO_PRENET_FUSE) != 0;
         unsigned char* const dH0 = ws + L.dH_of(-1);
         if (!unfused) {
             constexpr int RS = 2 * Prec<T>::KG;
@@ -1298,11 +1306,25 @@ int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
     ge2e_handle h = new (std::nothrow) ge2e_handle_s();
     if (!h) return GE2E_EINVAL;
     h->cfg = *cfg;
-    h->overlap = std::getenv("GE2E_NO_OVERLAP") ? 0 : 1;
+    h->overlap = opt(O_NO_OVERLAP) ? 0 : 1;
     build_params(h);
     *out = h;
     return 0;
 }
+
+int ge2e_set_option(const char* name, int value) {
+    if (!name) return GE2E_EINVAL;
+    for (int i = 0; i < O_COUNT; ++i)
+        if (std::strcmp(name, OPT_DEFS[i].name) == 0) { g_opt[i].store(value, std::memory_order_relaxed); return 0; }
+    return GE2E_EINVAL;
+}
+int ge2e_get_option(const char* name, int* value) {
+    if (!name || !value) return GE2E_EINVAL;
+    for (int i = 0; i < O_COUNT; ++i)
+        if (std::strcmp(name, OPT_DEFS[i].name) == 0) { *value = opt(i); return 0; }
+    return GE2E_EINVAL;
+}
+const char* ge2e_option_name(int index) { return index >= 0 && index < O_COUNT ? OPT_DEFS[index].name : nullptr; }
 
 int ge2e_destroy(ge2e_handle h) {
     if (!h) return 0;

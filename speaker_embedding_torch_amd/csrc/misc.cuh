@@ -140,10 +140,16 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnBwdArgs p) {
 
 // gradient buffer <- 0 in ONE launch (hipMemsetAsync splits a buffer whose size is not a multiple of 16 bytes into two fill kernels, each a
 // dependent launch at the head of the backward)
+// Any 4-byte-aligned buffer: up to three scalar stores bring the pointer to a 16-byte boundary, 16-byte stores do the body, scalar stores the rest.
 __global__ void __launch_bounds__(256) zero_f32_kernel(float* p, size_t n) {
-    const size_t n4 = n >> 2;
-    for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) ((f32x4*)p)[q] = f32x4{0, 0, 0, 0};
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.0f;
+    const size_t head = min(n, (size_t)((16 - ((uintptr_t)p & 15)) & 15) >> 2);
+    float* const b = p + head;
+    const size_t nb = n - head, n4 = nb >> 2;
+    for (size_t q = blockIdx.x * (size_t)256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) ((f32x4*)b)[q] = f32x4{0, 0, 0, 0};
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < head) p[threadIdx.x] = 0.0f;
+        if (threadIdx.x < (nb & 3)) b[(n4 << 2) + threadIdx.x] = 0.0f;
+    }
 }
 
 // dgamma / dbeta of a LayerNorm alone (the row part of its backward rides in the chained FFN backward kernel, ffn.cuh): column sums over all

@@ -45,8 +45,6 @@ struct WgradKsArgs {
     int rows_per_split;          // multiple of 32
     int tiles_n, tiles_k;        // 256 x 256 tiles along N and K
     int splits;                  // row slices; grid = 8 * tiles * ceil(splits / 8) blocks, the surplus ones exit at once
-    int flat_order;              // ablation (GE2E_WGRAD_KS_FLAT=1): round 2's order, tile = b % tiles -- the tiles of a slice on different XCDs
-    float* dW; int ldw;          // ATOMIC instantiation: the tile is added straight into dW[n][k] (no partial slab, no reduce pass)
 };
 
 template <typename T> __device__ __forceinline__ constexpr unsigned wk_one2();
@@ -69,7 +67,7 @@ __device__ __forceinline__ void wk_lds_retire(u32x4* f) {      // all 12 fragmen
 }
 
 // grid = 8 * tiles_n * tiles_k * ceil(splits / 8) blocks (<= one per CU) of 512 threads
-template <typename T, bool ATOMIC = false>
+template <typename T>
 __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage modes");
     constexpr int D = WK_D, NSTG = WK_NSTG;
@@ -82,8 +80,8 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     const int ntile = p.tiles_n * p.tiles_k;
     // XCD x = b & 7 holds row slices x, x + 8, ...; position j = b >> 3 inside the XCD walks the tiles of a slice first
     const int xj = blockIdx.x >> 3;
-    const int tile = p.flat_order ? (int)blockIdx.x % ntile : xj % ntile;
-    const int split = p.flat_order ? (int)blockIdx.x / ntile : (xj / ntile) * 8 + ((int)blockIdx.x & 7);
+    const int tile = xj % ntile;
+    const int split = (xj / ntile) * 8 + ((int)blockIdx.x & 7);
     if (split >= p.splits) return;                          // (whole block, before any barrier)
     const int n0 = (tile % p.tiles_n) * 256, k0 = (tile / p.tiles_n) * 256;
     const int rbeg = split * p.rows_per_split;
@@ -191,25 +189,14 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
     }
     wait_vmcnt<0>();                             // the stages issued past the end land before the block's LDS is released
 
-    if constexpr (ATOMIC) {
-        // ---- no partial slab: every accumulator register is one no-return float atomic per lane, 4 x 64 contiguous bytes per wave
-        // instruction (lanes i = 0..15 of one g are 16 consecutive k of row 4g + r).  dW (<= 1 MB) lives in the caches; the adds
-        // execute at the memory side while the next kernel's blocks start.
-        float* const dw = p.dW + (size_t)(n0 + 64 * wn + 4 * g) * p.ldw + k0 + 128 * wk + i;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) atomicAdd(dw + (size_t)(16 * mt + r) * p.ldw + 16 * nt, acc[mt][nt][r]);
-    } else {
+    // (Adding the tile straight into dW with float atomics instead -- no partial slab, no reduce pass -- was measured in round 3 and lost:
+    // 3.93 vs 3.77 ms per step; 64-byte atomic segments, 128 per wave.)
     // ---- partial tile in fragment order: part[split][tile][wave][mt][nt][lane] (16 B each): plain, fully coalesced stores
     f32x4* const out = (f32x4*)(p.part + ((size_t)split * ntile + tile) * WK_TILE_FLOATS) + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) __builtin_nontemporal_store(acc[mt][nt], out + (mt * 8 + nt) * 64);
-    }
     if (do_bias && i == 0) {                     // accb[mt][r] = sum_rows Y[.][n0 + 64 wn + 16 mt + 4g + r] (the same in every column i)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)

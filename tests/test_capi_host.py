@@ -170,3 +170,32 @@ def test_precision_a_hyper_parameter_file_asks_for():
     from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters
     hp = Load_Hyper_Parameters(os.path.join(REPO, "speaker_embedding_torch_amd", "Hyper_Parameters.yaml"))
     assert default_precision(hp) == "bf16"          # the shipped recipe = BASELINE.json configs[1]
+
+
+def test_options_are_an_api_not_the_environment():
+    """the development switches are ge2e_set_option entries with compiled-in defaults; no product source reads the
+    environment for them, and the loader forwards GE2E_<NAME> variables only under GE2E_DEV_SWITCHES=1."""
+    lib = _lib.load()
+    names = _lib.option_names()
+    assert "no_overlap" in names and "debug_bwd_stop" in names and len(names) == len(set(names))
+    header = open(os.path.join(REPO, "include", "ge2e_hip.h")).read()
+    for n in names:
+        assert f'"{n}"' in header, f"option {n} is not documented in include/ge2e_hip.h"
+    assert _lib.get_option("no_ws_gemm") == 0 and _lib.get_option("debug_bwd_stop") == -1
+    _lib.set_option("no_ws_gemm", 1)
+    try:
+        assert _lib.get_option("no_ws_gemm") == 1       # read at every call: nothing latched
+    finally:
+        _lib.set_option("no_ws_gemm", 0)
+    with pytest.raises(KeyError):
+        _lib.set_option("no_such_option", 1)
+    assert lib.ge2e_set_option(None, 1) != 0
+    csrc = os.path.join(REPO, "speaker_embedding_torch_amd", "csrc")
+    for f in os.listdir(csrc):
+        assert "getenv" not in open(os.path.join(csrc, f)).read(), f"{f} reads the environment"
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\nfrom speaker_embedding_torch_amd import _lib\nprint(_lib.get_option('no_kl_gemm'))" % REPO)
+    plain = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GE2E_NO_KL_GEMM="1"), capture_output=True, text=True, timeout=300)
+    dev = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GE2E_NO_KL_GEMM="1", GE2E_DEV_SWITCHES="1"), capture_output=True, text=True, timeout=300)
+    assert plain.returncode == 0 and plain.stdout.strip() == "0", plain.stderr[-500:]
+    assert dev.returncode == 0 and dev.stdout.strip() == "1", dev.stderr[-500:]

@@ -178,12 +178,13 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     stream = torch.cuda.current_stream().cuda_stream
 
     def run_backward(stop):
-        os.environ["GE2E_DEBUG_BWD_STOP"] = str(stop)
+        from speaker_embedding_torch_amd import _lib
+        _lib.set_option("debug_bwd_stop", stop)
         try:
             hnd.encoder_backward(stream, x, n, t, 1, ptrs, d_emb, grads, ws, seed, 0)
             torch.cuda.synchronize()
         finally:
-            del os.environ["GE2E_DEBUG_BWD_STOP"]
+            _lib.set_option("debug_bwd_stop", -1)
 
     run_backward(1)
     dy = tap("dHa.1", (R, d)).clone()                                     # dL/d(h2 of layer 1), written by the last layer's dgrad

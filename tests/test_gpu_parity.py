@@ -335,16 +335,17 @@ def test_deep_stacks_reuse_backward_scratch_behind_waits(mods, tmp_path, prec, l
     l % 2, dQKV l % 3) and the main chain must WAIT for the weight-gradient stream's reader of a buffer before overwriting it
     (`sc.wait(g_set1 / g_dF / g_set2 / g_dQKV)` in backward_body).  A full train step against the oracle on a NaN-poisoned
     workspace, three ways: as shipped; with the weight-gradient stream held back 400 us after every fork
-    (GE2E_DEBUG_SIDE_DELAY_US: a missing wait then overwrites an operand the weight gradient has not read yet) and one
-    wgrad_ks block per CU (GE2E_WGRAD_KS_BLOCKS=256); and serialised on one stream (GE2E_NO_OVERLAP).  All three must agree
+    (option debug_side_delay_us: a missing wait then overwrites an operand the weight gradient has not read yet) and one
+    wgrad_ks block per CU (wgrad_ks_blocks = 256); and serialised on one stream (no_overlap).  All three must agree
     with each other to fp32 summation order and with the oracle within the mode's bound."""
     import subprocess, sys as _sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     n, t = 24, 128
     scale = 1024.0 if prec == "fp16" else 1.0
     res = {}
-    for tag, extra in (("shipped", {}), ("delayed", {"GE2E_DEBUG_SIDE_DELAY_US": "400", "GE2E_WGRAD_KS_BLOCKS": "256"}),
-                       ("serial", {"GE2E_NO_OVERLAP": "1"})):
+    dev = {"GE2E_DEV_SWITCHES": "1"}        # the loader forwards GE2E_<OPTION> to ge2e_set_option only with this set
+    for tag, extra in (("shipped", {}), ("delayed", dict(dev, GE2E_DEBUG_SIDE_DELAY_US="400", GE2E_WGRAD_KS_BLOCKS="256")),
+                       ("serial", dict(dev, GE2E_NO_OVERLAP="1"))):
         out = str(tmp_path / f"{tag}.npz")
         code = _DEPTH_SCRIPT.format(repo=repo, tests=os.path.join(repo, "tests"), out=out, prec=prec, layers=layers, n=n, t=t, scale=scale)
         r = subprocess.run([_sys.executable, "-c", code], env=dict(os.environ, **extra), cwd=repo, capture_output=True, text=True, timeout=900)
@@ -609,21 +610,44 @@ def test_error_behaviour(mods):
 # ------------------------------------------------------------------------------------------ fp16 mel input (row f2)
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_fp16_mel_input_is_bitwise_the_widened_input(mods, prec):
-    """ge2e_encoder_forward_mel16: patterns are fp16 on disk (Pattern_Generator.py:191-198); feeding the fp16 batch and
-    feeding its float32 widening (what Datasets.py:84 does on the host) must give the same bits, forward and backward."""
+    """ge2e_encoder_forward_mel16 (SURVEY row f2): patterns are fp16 on disk (Pattern_Generator.py:191-198); feeding the fp16 batch and
+    feeding its float32 widening (what Datasets.py:84 does on the host) must give the same bits, forward and backward -- AND both must
+    be what the oracle computes from the widened batch (same dropout stream): d-vectors within the mode's bound (fp32: the
+    north_star 1e-4), every parameter gradient within the mode's gradient bound."""
     GE2E, GE2E_Loss = mods
+    p, P = 0.1, 3
     x16 = torch.from_numpy(O.formula_mel(3, 12, 80, 77, logmel=True)).half().cuda()
     outs = []
     for x in (x16, x16.float()):
-        m, _, _ = build(GE2E, prec, 0.1)
+        m, params, pe = build(GE2E, prec, p)
         m.train()
         emb = m(x)
-        GE2E_Loss().cuda()(emb, 3).backward()
-        outs.append((emb.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+        GE2E_Loss().cuda()(emb, P).backward()
+        outs.append((emb.detach().clone(), {n_: q.grad.clone() for n_, q in m.named_parameters()}))
     assert torch.equal(outs[0][0], outs[1][0])
     # weight gradients use fp32 atomics (summation order varies run to run): equal to rounding, not bitwise
-    for a, b in zip(outs[0][1], outs[1][1]):
-        assert rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    for k in outs[0][1]:
+        assert rel_l2(outs[0][1][k].cpu().numpy(), outs[1][1][k].cpu().numpy()) < 1e-5, k
+    # against the oracle on the widened values (reference Datasets.py:84: the collater's FloatTensor of the fp16 patterns)
+    x_np = x16.float().cpu().numpy()
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=p, p_tf=p, pe=pe)
+    _, lc = O.loss_forward(emb_ref, P)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    e = outs[0][0].cpu().numpy()
+    if prec == "fp32":
+        assert np.abs(e - emb_ref).max() < 1e-5 and rel_l2(e, emb_ref) < 1e-4
+        tol = 2e-3 if _relu_margin_ok(c) else 0.2
+        for k, g in outs[0][1].items():
+            assert rel_l2(g.cpu().numpy(), grads_ref[k]) < tol, k
+    else:
+        assert np.abs(e - emb_ref).max() < 6e-3 and rel_l2(e, emb_ref) < 2e-2
+        for k, g in outs[0][1].items():
+            g, r = g.cpu().numpy().ravel().astype(np.float64), grads_ref[k].ravel().astype(np.float64)
+            if g.size == 1:
+                assert abs(g[0] - r[0]) < 0.3 * np.linalg.norm(grads_ref["prenet.bias"]), k
+                continue
+            cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            assert cos > 0.99 and rel_l2(g, r) < 0.15, (k, cos, rel_l2(g, r))
 
 
 def test_device_prefetcher_order_and_values(mods):
@@ -657,14 +681,14 @@ np.savez({out!r}, **out)
 
 
 def test_bf16_streaming_and_tiled_kernels_agree(mods, tmp_path):
-    """The bf16 mode runs the K=256 products on gemm_ws_kernel and FFN2+LN on gemm_kl_kernel; GE2E_NO_WS_GEMM /
-    GE2E_NO_KL_GEMM put the same step on the tiled gemm_nt_kernel (the kernels the fp32 parity mode uses).  Same
+    """The bf16 mode runs the K=256 products on gemm_ws_kernel and FFN2+LN on gemm_kl_kernel; the options no_ws_gemm /
+    no_kl_gemm put the same step on the tiled gemm_nt_kernel (the kernels the fp32 parity mode uses).  Same
     dropout stream, same inputs, ragged rows (12 x 77 = 924: not a multiple of the 16- and 128-row tiles): the
     projections are bit-identical between the two, the LayerNorm statistics are summed in a different order."""
     import subprocess, sys as _sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for tag, extra in (("stream", {}), ("tiled", {"GE2E_NO_WS_GEMM": "1", "GE2E_NO_KL_GEMM": "1"})):
+    for tag, extra in (("stream", {}), ("tiled", {"GE2E_DEV_SWITCHES": "1", "GE2E_NO_WS_GEMM": "1", "GE2E_NO_KL_GEMM": "1"})):
         out = str(tmp_path / f"{tag}.npz")
         env = dict(os.environ, **extra)
         code = _PATH_SCRIPT.format(repo=repo, tests=os.path.join(repo, "tests"), out=out)

@@ -390,3 +390,85 @@ def test_many_steps_enqueued_without_a_host_sync(tmp_path):
     assert torch.isfinite(vals).all()
     hnd = tr.model._handle()
     assert hnd is not None and tr.steps == 60
+
+
+# ------------------------------------------------------------------------------------------ the RCCL bucket schedule on one GPU
+_NCCL_SCRIPT = r"""
+import os, sys, numpy as np, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, os.path.join({repo!r}, "tests"))
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{port}", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+from oracle import ge2e_oracle as O
+from speaker_embedding_torch_amd import distributed as D
+from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+import test_gpu_parity as tp
+D.init_distributed(0, 1, "nccl")                              # reference distributed.py:28-36; backend "nccl" IS RCCL on ROCm
+out = {{}}
+for tag, n, t, P in (("full", 960, 160, 15), ("small", 12, 77, 3)):
+    m, params, pe = tp.build(GE2E, "bf16", 0.1)
+    m.train()
+    x = torch.from_numpy(O.formula_mel(5, n, 80, t, logmel=True)).cuda()
+    crit = GE2E_Loss().cuda()
+    grads = {{}}
+    for mode in ("plain", "nccl"):
+        if mode == "nccl":
+            D.apply_gradient_allreduce(m)                    # broadcast + GradSync: every backward from here on reports buckets
+        for q in m.parameters():
+            q.grad = None
+        emb = m(x)
+        crit(emb, P).backward()
+        torch.cuda.synchronize()
+        grads[mode] = torch.cat([q.grad.flatten() for q in m.parameters()]).cpu().numpy()
+        out[tag + "_emb_" + mode] = emb.detach().cpu().numpy()
+    sync = m._grad_sync
+    assert sync is not None and torch.distributed.get_backend() == "nccl" and sync._avg
+    out[tag + "_buckets"] = np.array(sync.buckets_seen, dtype=np.int64)
+    hnd = m._handle()
+    st = torch.cuda.current_stream().cuda_stream
+    out[tag + "_side_stream_differs"] = np.array([int(hnd.bucket_stream(st) not in (0, st))])
+    out[tag + "_g_plain"], out[tag + "_g_nccl"] = grads["plain"], grads["nccl"]
+torch.distributed.destroy_process_group()
+np.savez({out!r}, **out)
+"""
+
+
+def test_bucket_schedule_through_a_one_rank_rccl_group(tmp_path):
+    """VERDICT r3 #3 / next-round 4b.  With a bucket callback the backward runs a DIFFERENT schedule from the benchmarked one (the norm2
+    column sums stay on the weight-gradient stream, every bucket forks) and `GradSync` issues `all_reduce(AVG, async_op=True)` with the
+    library's weight-gradient stream current (`ExternalStream(ge2e_bucket_stream)`, speaker_embedding_torch_amd/distributed.py).  This pool has
+    one GPU per box, so the only RCCL execution possible is a 1-rank `nccl` group: a fresh process runs configs[1] (64 x 15 x 160, bf16,
+    dropout on) plainly and through `apply_gradient_allreduce` (reference distributed.py:73-125) and the two must agree to fp32 summation
+    order; the same at 12 x 77, where the oracle (same dropout stream) finishes in seconds, against the oracle within the bf16 bounds."""
+    import subprocess
+    out = str(tmp_path / "nccl.npz")
+    code = _NCCL_SCRIPT.format(repo=REPO, port=29700 + os.getpid() % 2000, out=out)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=REPO, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = dict(np.load(out))
+    for tag in ("full", "small"):
+        assert np.array_equal(res[tag + "_emb_plain"], res[tag + "_emb_nccl"]), tag            # forward: no atomics, bitwise
+        b = res[tag + "_buckets"]
+        total = res[tag + "_g_plain"].size
+        assert len(b) == 5 and int(b[:, 1].sum()) == total and b[0, 0] + b[0, 1] == total and b[-1, 0] == 0
+        assert int(res[tag + "_side_stream_differs"][0]) == 1, "the all-reduce must run behind the weight-gradient stream, not the caller's"
+        assert np.isfinite(res[tag + "_g_nccl"]).all()
+        assert rel_l2(res[tag + "_g_nccl"], res[tag + "_g_plain"]) < 1e-4, tag              # mean over ONE rank == the rank's own gradient
+    # the oracle on the small case: the bf16 bounds of test_bf16_train_step_vs_oracle
+    from speaker_embedding_torch_amd.Modules import GE2E
+    import test_gpu_parity as tp
+    m, params, pe = tp.build(GE2E, "bf16", 0.1)
+    x_np = O.formula_mel(5, 12, 80, 77, logmel=True)
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=0.1, p_tf=0.1, pe=pe)
+    _, lc = O.loss_forward(emb_ref, 3)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    assert rel_l2(res["small_emb_nccl"], emb_ref) < 2e-2
+    flat, off = res["small_g_nccl"].astype(np.float64), 0
+    for name, prm in m.named_parameters():
+        k = prm.numel()
+        g, rr = flat[off:off + k], grads_ref[name].ravel().astype(np.float64)
+        off += k
+        if k == 1:
+            assert abs(g[0] - rr[0]) < 0.3 * np.linalg.norm(grads_ref["prenet.bias"]), name
+            continue
+        cos = float(g @ rr / max(np.linalg.norm(g) * np.linalg.norm(rr), 1e-30))
+        assert cos > 0.99 and rel_l2(g, rr) < 0.15, (name, cos, rel_l2(g, rr))

@@ -1,7 +1,9 @@
 #!/bin/bash
-# A/B of bench.py under different environment switches on ONE box (run-to-run noise between boxes is ~1 %):
+# A/B of bench.py under different library options on ONE box (run-to-run noise between boxes is ~1 %):
 #   bash tools/ab.sh "base:" "wv8:GE2E_FFN_WV=8" ...        (name:ENV=VALUE[ ENV=VALUE]); two interleaved repetitions
+# GE2E_DEV_SWITCHES=1 makes the ctypes loader forward GE2E_<NAME>=value to ge2e_set_option (the library itself never reads the environment).
 set -e
+export GE2E_DEV_SWITCHES=1
 mkdir -p gpurun_out/ab
 [ $# -gt 0 ] || set -- "base:"
 for rep in 1 2; do

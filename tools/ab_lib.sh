@@ -1,12 +1,12 @@
 #!/bin/bash
-# A/B of two BUILDS on one box: bash tools/ab_lib.sh a b   (variants from tools/build_variant.py: tools/abl/<name>/{libge2e_hip.so,csrc/*} are
-# copied into place per run, so the loader's source-hash check holds; the GPU box's copy of the tree is left with the LAST variant)
+# A/B of two BUILDS on one box: bash tools/ab_lib.sh a b   (variants from tools/build_variant.py under tools/abl/<name>/).  A variant is loaded
+# through GE2E_LIB_OVERRIDE (honoured only with GE2E_DEV_SWITCHES=1; the loader prints which binary it took): the in-tree library is never touched.
 set -e
+export GE2E_DEV_SWITCHES=1
 mkdir -p gpurun_out/ab
 for rep in 1 2 3; do
 for v in "$@"; do
-  cp tools/abl/$v/libge2e_hip.so speaker_embedding_torch_amd/libge2e_hip.so; cp tools/abl/$v/csrc/* speaker_embedding_torch_amd/csrc/
-  timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline ${AB_ARGS} > gpurun_out/ab/lib_${v}_$rep.json 2> gpurun_out/ab/lib_${v}_$rep.err || { tail -5 gpurun_out/ab/lib_${v}_$rep.err; exit 1; }
+  GE2E_LIB_OVERRIDE=$PWD/tools/abl/$v/libge2e_hip.so timeout -k 10 300 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-roofline ${AB_ARGS} > gpurun_out/ab/lib_${v}_$rep.json 2> gpurun_out/ab/lib_${v}_$rep.err || { tail -5 gpurun_out/ab/lib_${v}_$rep.err; exit 1; }
   python - <<PY
 import json
 d=json.loads(open("gpurun_out/ab/lib_${v}_$rep.json").read().strip().splitlines()[-1])

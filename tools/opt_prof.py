@@ -1,9 +1,10 @@
 import sys, time, torch, cProfile, pstats, os
-sys.path.insert(0, '/root/repo')
+ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, ROOT)
 import bench
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
 from speaker_embedding_torch_amd.Optim import FusedClipAdamW
-hp = bench.Load_Hyper_Parameters(os.path.join('/root/repo', 'speaker_embedding_torch_amd', 'Hyper_Parameters.yaml'))
+hp = bench.Load_Hyper_Parameters(os.path.join(ROOT, 'speaker_embedding_torch_amd', 'Hyper_Parameters.yaml'))
 dev = torch.device('cuda')
 model = GE2E(hp, precision='bf16', seed=1234).to(dev); crit = GE2E_Loss().to(dev)
 opt = FusedClipAdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)

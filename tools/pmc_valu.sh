@@ -3,7 +3,7 @@
 #   valu_share = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs): issue cycles of vector instructions against the SIMD cycles of the launch
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-valu}
-export GE2E_NO_OVERLAP=1
+export GE2E_DEV_SWITCHES=1 GE2E_NO_OVERLAP=1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_$tag -o v -- python3 bench.py --steps 2 --warmup 1 --no-roofline --no-cpu-baseline > gpurun_out/pmc_$tag.log 2>&1 || { tail -5 gpurun_out/pmc_$tag.log; exit 1; }
 python3 - <<PY
 import csv, glob, collections
