@@ -414,6 +414,7 @@ for tag, n, t, P in (("full", 960, 160, 15), ("small", 12, 77, 3)):
             D.apply_gradient_allreduce(m)                    # broadcast + GradSync: every backward from here on reports buckets
         for q in m.parameters():
             q.grad = None
+        m._step = 0                                          # the dropout stream follows the step counter: both runs are step 0
         emb = m(x)
         crit(emb, P).backward()
         torch.cuda.synchronize()

@@ -1,9 +1,15 @@
-// Phase ablation of attn_bwd_kernel at the headline shape (development tool).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I speaker_embedding_torch_amd/csrc tools/attn_bwd_bench.hip -o tools/attn_bwd_bench
+// Attention backward variants at the headline shape, same inputs (a real forward's o / lse), outputs compared, each timed alone on the chip
+// (development tool): attn_bwd_kernel as round 3 shipped it, its QL form (Q tile LDS-resident, dO / O rows prefetched: round 4), and
+// tools/attention_bwd1.cuh (every score evaluated once; measured and NOT shipped: profiles/r04_ab_log.txt).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I speaker_embedding_torch_amd/csrc -I tools tools/attn_bwd_bench.hip -o tools/attn_bwd_bench
+//   tools/attn_bwd_bench [T] [n]       (T <= 288; default 160 frames, 960 utterances)
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
-#include "attention.cuh"
-#include "experimental/attention_v0.cuh"
+#include <cstring>
+#include <algorithm>
+#include <vector>
+#include "attention_bwd1.cuh"
 using namespace ge2e;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 template <typename K> float time_kernel(K launch, int iters = 10) {
@@ -15,59 +21,115 @@ template <typename K> float time_kernel(K launch, int iters = 10) {
     float ms; CHECK(hipEventElapsedTime(&ms, a, b)); CHECK(hipGetLastError());
     return ms / iters * 1e3f;
 }
-__global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
+__global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed, float amp) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        p[i] = (bf16_t)(((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f);
+        p[i] = (bf16_t)((((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f) * amp);
 }
-template <int ABL> void run0(const AttnArgs& a0, int n, const char* tag, size_t extra_lds = 0) {
-    using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    v0::AttnArgs a{}; a.qkv = a0.qkv; a.o = a0.o; a.lse = a0.lse; a.dout = a0.dout; a.dqkv = a0.dqkv; a.T = a0.T; a.H = a0.H; a.D = a0.D; a.scale = a0.scale; a.drop = a0.drop;
-    const size_t sb = 2 * (size_t)TP * G::LD + 2 * TP * 4 + TP * (TP / 32) * 4 + extra_lds;
-    auto kb = v0::attn_bwd_kernel<T, KT, false, 5, ABL>;
+static float bf(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
+
+template <int KT, bool PAD, bool DROP> void run(AttnArgs a, int n, bf16_t* dq_old, bf16_t* dq_new, size_t R) {
+    using T = bf16_t; using G = attn::Geo<T>; constexpr int TP = 32 * KT;
+    {   // a real forward: o and lse
+        auto kf = attn_fwd_kernel<T, KT, PAD, DROP, 5>;
+        const size_t sf = 2 * (size_t)TP * G::LD;
+        CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
+        const int nw = std::min(8, ((a.T + 15) / 16 + 1) / 2);
+        hipLaunchKernelGGL(kf, dim3(n * 4), dim3(64 * nw), sf, 0, a);
+        CHECK(hipDeviceSynchronize());
+    }
+    const int nw = std::min(8, ((a.T + 15) / 16 + 1) / 2);
+    size_t sb = 2 * (size_t)TP * G::LD + 2 * TP * 4 + (DROP ? TP * (TP / 4) : 0);
+    if (nw >= 5 && 3 * sb <= (size_t)160 * 1024) sb = (size_t)160 * 1024 / 3 + 1024;
+    auto kb = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 2>;
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
-    printf("v0  %-40s abl %2d  %7.1f us\n", tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(320), sb, 0, a); }));
+    a.dqkv = dq_old;
+    const float t_old = time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(64 * nw), sb, 0, a); });
+    if constexpr (KT <= 5) {       // QL form: three tiles + keep bytes; scheduling-barrier spacing 1 / 2 / 5 key groups
+        const size_t sq = 3 * (size_t)TP * G::LD + 2 * TP * 4 + (DROP ? TP * (TP / 4) : 0);
+        auto time_ql = [&](auto kq, const char* tag) {
+            CHECK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sq));
+            int occq = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occq, (const void*)kq, 64 * KT, sq));
+            CHECK(hipMemset(dq_new, 0xFF, R * 768 * 2));
+            a.dqkv = dq_new;
+            const float t_ql = time_kernel([&]() { hipLaunchKernelGGL(kq, dim3(n * 4), dim3(64 * KT), sq, 0, a); });
+            CHECK(hipDeviceSynchronize());
+            std::vector<unsigned short> ho(R * 768), hn(R * 768);
+            AttnArgs s = a; s.dqkv = dq_old;
+            hipLaunchKernelGGL(kb, dim3(n * 4), dim3(64 * nw), sb, 0, s);
+            CHECK(hipDeviceSynchronize());
+            CHECK(hipMemcpy(ho.data(), dq_old, R * 768 * 2, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hn.data(), dq_new, R * 768 * 2, hipMemcpyDeviceToHost));
+            size_t diff = 0;
+            for (size_t e = 0; e < R * 768; ++e) diff += ho[e] != hn[e];
+            printf("T %3d KT %d pad %d drop %d | old %7.1f us | %s %7.1f us (%zu B LDS, %d blocks/CU), %zu of %zu output elements differ from old\n", a.T, KT, (int)PAD, (int)DROP, t_old, tag, t_ql, sq, occq, diff, R * 768);
+        };
+        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, true>, "QL sbe1");
+        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3, true>, "QL sbe2");
+        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 5, 0, 3, true>, "QL sbe5");
+        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, true, true>, "QL pipe sbe1");
+        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3, true, true>, "QL pipe sbe2");
+        CHECK(hipMemset(dq_new, 0xFF, R * 768 * 2));
+    }
+    {
+        auto k2 = attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3>; auto k5 = attn_bwd_kernel<T, KT, PAD, DROP, 5, 0, 3>;
+        CHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb)); CHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
+        AttnArgs s = a; s.dqkv = dq_old;
+        const float t2 = time_kernel([&]() { hipLaunchKernelGGL(k2, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
+        const float t5 = time_kernel([&]() { hipLaunchKernelGGL(k5, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
+        auto kp = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, false, true>;
+        CHECK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
+        const float tp = time_kernel([&]() { hipLaunchKernelGGL(kp, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
+        printf("        old form with scheduling barriers every 2 / 5 groups: %7.1f / %7.1f us; pipelined by hand (sbe 1): %7.1f us\n", t2, t5, tp);
+    }
+    using PL = attn1::Plan<KT>;
+    a.dqkv = dq_new;
+    auto k1 = attn_bwd1_kernel<T, KT, PAD, DROP>;
+    CHECK(hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, PL::SMEM));
+    int occ = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k1, 64 * KT, PL::SMEM));
+    const float t_new = time_kernel([&]() { hipLaunchKernelGGL(k1, dim3(n * 4), dim3(64 * KT), PL::SMEM, 0, a); });
+    AttnArgs s = a; s.dqkv = dq_old;
+    const float t_a = 0, t_b = 0, t_c = 0, t_d = 0;
+    if (getenv("ATTN1_ABL")) {
+    }
+    hipLaunchKernelGGL(kb, dim3(n * 4), dim3(64 * nw), sb, 0, s);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned short> ho(R * 768), hn(R * 768);
+    CHECK(hipMemcpy(ho.data(), dq_old, R * 768 * 2, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hn.data(), dq_new, R * 768 * 2, hipMemcpyDeviceToHost));
+    const char* nm[3] = {"dQ", "dK", "dV"};
+    (void)t_a; (void)t_b; (void)t_c; (void)t_d;
+    printf("        single-evaluation kernel %7.1f us (QP %d, %d B LDS, %d blocks/CU) |", t_new, PL::QP, PL::SMEM, occ);
+    for (int part = 0; part < 3; ++part) {
+        double num = 0, den = 0, mx = 0;
+        for (size_t r = 0; r < R; ++r)
+            for (int c = 0; c < 256; ++c) {
+                const double x = bf(ho[r * 768 + part * 256 + c]), y = bf(hn[r * 768 + part * 256 + c]);
+                num += (x - y) * (x - y); den += x * x; mx = std::max(mx, std::fabs(x - y));
+            }
+        printf(" %s rel %.2e max %.2e", nm[part], std::sqrt(num / std::max(den, 1e-30)), mx);
+    }
+    printf("\n");
 }
-template <int ABL> void runf0(const AttnArgs& a0, int n, const char* tag, size_t extra_lds = 0) {
-    using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    v0::AttnArgs a{}; a.qkv = a0.qkv; a.o = a0.o; a.lse = a0.lse; a.dout = a0.dout; a.dqkv = a0.dqkv; a.T = a0.T; a.H = a0.H; a.D = a0.D; a.scale = a0.scale; a.drop = a0.drop;
-    const size_t sf = 2 * (size_t)TP * G::LD + extra_lds;
-    auto kf = v0::attn_fwd_kernel<T, KT, false, 1, ABL>;
-    CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
-    printf("v0 fwd %-37s abl %2d  %7.1f us\n", tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kf, dim3(n * 4), dim3(320), sf, 0, a); }));
-}
-template <int ABL, bool DROP = true, int SCH = 5, int MINB = 1> void run(const AttnArgs& a, int n, const char* tag, size_t extra_lds = 0) {
-    using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    const size_t sb = 2 * (size_t)TP * G::LD + 2 * TP * 4 + TP * (TP / 4) + extra_lds;
-    auto kb = attn_bwd_kernel<T, KT, false, DROP, SCH, ABL, MINB>;
-    CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
-    printf("sbe%d minb%d %-34s abl %2d  %7.1f us\n", SCH, MINB, tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(320), sb, 0, a); }));
-}
-template <int ABL, bool DROP = true, int SCH = 1> void runf(const AttnArgs& a, int n, const char* tag, size_t extra_lds = 0) {
-    using T = bf16_t; using G = attn::Geo<T>; constexpr int KT = 5, TP = 160;
-    const size_t sf = 2 * (size_t)TP * G::LD + extra_lds;
-    auto kf = attn_fwd_kernel<T, KT, false, DROP, SCH, ABL>;
-    CHECK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sf));
-    printf("sch%d fwd %-36s abl %2d  %7.1f us\n", SCH, tag, ABL, time_kernel([&]() { hipLaunchKernelGGL(kf, dim3(n * 4), dim3(320), sf, 0, a); }));
+template <int KT> void run_kt(const AttnArgs& a, int n, bf16_t* d0, bf16_t* d1, size_t R) {
+    const bool pad = a.T % 32 != 0;
+    AttnArgs nd = a; nd.drop = Drop{0u, 0u, 1.0f};
+    if (pad) { run<KT, true, true>(a, n, d0, d1, R); run<KT, true, false>(nd, n, d0, d1, R); }
+    else { run<KT, false, true>(a, n, d0, d1, R); run<KT, false, false>(nd, n, d0, d1, R); }
 }
 int main(int argc, char** argv) {
-    const int n = 960, T_ = 160, D = 256; const size_t R = (size_t)n * T_;
-    bf16_t *qkv, *o, *dout, *dqkv; float* lse;
-    CHECK(hipMalloc(&qkv, R * 768 * 2)); CHECK(hipMalloc(&o, R * 256 * 2)); CHECK(hipMalloc(&dout, R * 256 * 2)); CHECK(hipMalloc(&dqkv, R * 768 * 2)); CHECK(hipMalloc(&lse, R * 16));
-    fill_bf16<<<2048, 256>>>(qkv, R * 768, 1); fill_bf16<<<2048, 256>>>(dout, R * 256, 2); fill_bf16<<<2048, 256>>>(o, R * 256, 3); CHECK(hipMemset(lse, 0, R * 16)); CHECK(hipDeviceSynchronize());
-    AttnArgs a{}; a.qkv = qkv; a.o = o; a.dout = dout; a.dqkv = dqkv; a.T = T_; a.H = 4; a.D = D; a.scale = 0.125f; a.lse = lse;
-    a.drop = Drop{12345u, 6553u, 1.1111f};
-    if (argc > 1) {      // PMC mode: few launches of the variants under study
-        run0<0>(a, n, "full"); run<0, true, 5, 1>(a, n, "full"); run<0, true, 5, 2>(a, n, "full");
-        return 0;
-    }
-    for (int rep = 0; rep < 2; ++rep) {
-        run0<0>(a, n, "full"); run<0, true, 5, 1>(a, n, "full"); run<0, true, 5, 2>(a, n, "full"); run<0, true, 1, 2>(a, n, "full"); run<0, true, 2, 2>(a, n, "full");
-        run0<1>(a, n, "phase A only"); run<1, true, 5, 1>(a, n, "phase A only"); run<1, true, 5, 2>(a, n, "phase A only");
-        run0<2>(a, n, "phase B only"); run<2, true, 5, 1>(a, n, "phase B only"); run<2, true, 5, 2>(a, n, "phase B only");
-        run0<4>(a, n, "no dropout"); run<0, false, 5, 1>(a, n, "no dropout"); run<0, false, 5, 2>(a, n, "no dropout");
-        run0<3>(a, n, "tile loads + barriers only");
-        runf0<0>(a, n, "full"); runf<0, true, 1>(a, n, "full"); runf<0, true, 2>(a, n, "full"); runf<0, true, 5>(a, n, "full");
-        runf0<2>(a, n, "no dropout"); runf<0, false, 1>(a, n, "no dropout");
+    const int T_ = argc > 1 ? atoi(argv[1]) : 160, n = argc > 2 ? atoi(argv[2]) : 960, D = 256; const size_t R = (size_t)n * T_;
+    bf16_t *qkv, *o, *dout, *d0, *d1; float* lse;
+    CHECK(hipMalloc(&qkv, R * 768 * 2)); CHECK(hipMalloc(&o, R * 256 * 2)); CHECK(hipMalloc(&dout, R * 256 * 2)); CHECK(hipMalloc(&d0, R * 768 * 2)); CHECK(hipMalloc(&d1, R * 768 * 2)); CHECK(hipMalloc(&lse, R * 16));
+    fill_bf16<<<2048, 256>>>(qkv, R * 768, 1, 2.0f); fill_bf16<<<2048, 256>>>(dout, R * 256, 2, 1.0f); CHECK(hipMemset(d0, 0xFF, R * 768 * 2)); CHECK(hipMemset(d1, 0xFF, R * 768 * 2)); CHECK(hipDeviceSynchronize());
+    AttnArgs a{}; a.qkv = qkv; a.o = o; a.dout = dout; a.T = T_; a.H = 4; a.D = D; a.scale = 0.125f; a.lse = lse;
+    a.drop = Drop{12345u, 6553u, 1.0f / 0.9f};
+    switch ((T_ + 31) / 32) {
+        case 3: run_kt<3>(a, n, d0, d1, R); break;
+        case 4: run_kt<4>(a, n, d0, d1, R); break;
+        case 5: run_kt<5>(a, n, d0, d1, R); break;
+        case 6: run_kt<6>(a, n, d0, d1, R); break;
+        case 7: run_kt<7>(a, n, d0, d1, R); break;
+        case 8: run_kt<8>(a, n, d0, d1, R); break;
+        case 9: run_kt<9>(a, n, d0, d1, R); break;
+        default: printf("T out of range\n"); return 1;
     }
     return 0;
 }
