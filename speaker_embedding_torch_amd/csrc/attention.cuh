@@ -179,26 +179,16 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 //   Phase B (wave owns 16 keys;    Q, dO in LDS): dV^T += dO^T Pd, dK^T += Q^T dS.
 // With dropout, dS = P (keep dP / (1 - p) - delta) scale is evaluated as P . fma(keep ? dP : 0, scale / (1 - p), - delta scale), and dV
 // accumulates the UNSCALED kept probabilities (its 1 / (1 - p) is applied once to the finished accumulators).
-// MINB: waves per SIMD the register allocation must allow (launch bound).
-// QL (round 4; 16-bit modes, launched with one wave per 32 frames, T <= 160): the Q tile is LDS-resident from the start, next to K and V
-//   (three tiles + the keep bytes = 68 KB at 160 frames: still two blocks per CU).  Phase A then takes its query fragments from LDS and
-//   prefetches the dO / O rows of BOTH of the wave's query tiles (delta on the spot) before the first barrier, so no tile starts with a
-//   global-memory round trip; phase B takes its K rows from the K tile and its V rows from the V tile (read before the dO tile replaces
-//   it) -- only the dO tile is fetched a second time.  HBM / L2 fetches per launch: 6 activation tiles instead of 8.
+// MINB: blocks per CU the register allocation must allow (launch bound).
 // ABL (development only, tools/attn_bwd_bench.hip): 1 no phase B, 2 no phase A, 8 no exp
-// PIPE (round 4): the score MFMAs (S, dP) of key / query group g + 1 and the transposed fragments of group g are issued BEFORE the vector work
-//   of group g (software pipeline by hand: the compiler's schedule runs the groups one after the other, each paying its LDS and MFMA
-//   latencies with 2.5 waves per SIMD to cover them).
-template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 5, int ABL = 0, int MINB = 1, bool QL = false, bool PIPE = false>
-__global__ void __launch_bounds__(QL ? 64 * KT : 512, MINB) attn_bwd_kernel(const AttnArgs p) {
+template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 5, int ABL = 0, int MINB = 1>
+__global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
     using G = attn::Geo<T>;
     constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
-    static_assert(!QL || sizeof(T) == 2, "QL: 16-bit storage modes");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const bufA = smem;
     unsigned char* const bufB = smem + TP * G::LD;
-    unsigned char* const bufC = smem + 2 * TP * G::LD;        // QL: the Q tile
-    float* const st_l = (float*)(smem + (QL ? 3 : 2) * TP * G::LD);     // lse (times ExpK) per query of this head
+    float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse (times ExpK) per query of this head
     float* const st_d = st_l + TP;                            // delta * scale per query
     // The 16-bit modes hash the dropout keep bits once (phase A) and hand them to phase B through LDS; fp32 mode (parity
     // path; its K/V tiles already fill the LDS at 288 frames) re-hashes in phase B instead.  One BYTE per (4 keys, query), key
@@ -222,83 +212,47 @@ __global__ void __launch_bounds__(QL ? 64 * KT : 512, MINB) attn_bwd_kernel(cons
     // ---------------------------------------------------------------- phase A
     attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
     attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
-    if constexpr (QL) attn::load_tile<T>(bufC, qbase, ldq, p.T, TP);
     for (int q = threadIdx.x; q < TP; q += blockDim.x) {
         st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
         st_d[q] = 0.0f;          // padded queries: phase B multiplies (dP - delta) by P = 0, so delta must be finite
     }
     const float ck = p.scale * ExpK<T>::K;
     const float sds = DROP ? p.scale * p.drop.scale : p.scale;
-    // rows of dO (and O: delta = dO . O) of query tile qt, straight from global memory
-    auto load_do_delta = [&](int qt, u32x4* dof) -> float {
-        const int qrow = qt * 16 + i;
-        const bool vq = qrow < p.T;
-        attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
-        u32x4 of[G::NKG];
-        attn::load_row_frags<T>(of, obase, ldo, qrow, vq, g);
-        float delta = 0.0f;
-#pragma unroll
-        for (int k = 0; k < G::NKG; ++k) {
-            const T* a = (const T*)&dof[k];
-            const T* b = (const T*)&of[k];
-#pragma unroll
-            for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
-        }
-        return cross4_sum(delta) * p.scale;
-    };
-    constexpr int NPRE = QL ? 2 : 1;                          // QL: a wave has at most two query (key) tiles: wave and wave + nw
-    [[maybe_unused]] u32x4 dofp[NPRE][G::NKG];
-    [[maybe_unused]] float dscp[NPRE];
-    if constexpr (QL) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) dscp[s] = load_do_delta(wave + s * nw, dofp[s]);
-    }
     __syncthreads();
-    for (int s = 0, qt = wave; qt * 16 < p.T && !(ABL & 2); ++s, qt += nw) {       // wave-uniform loop: EXEC stays full
+    for (int qt = wave; qt * 16 < p.T && !(ABL & 2); qt += nw) {
         const int qrow = qt * 16 + i;
         const bool vq = !PAD || qrow < p.T;
         u32x4 qf[G::NKG], dof[G::NKG];
-        float dsc;
-        if constexpr (QL) {
+        attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
+        attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
+        float delta = 0.0f;
+        {
+            u32x4 of[G::NKG];
+            attn::load_row_frags<T>(of, obase, ldo, qrow, vq, g);
 #pragma unroll
-            for (int k = 0; k < G::NKG; ++k) { qf[k] = lds16(bufC + attn::toff<T>(qrow, k * 4 + g)); dof[k] = s == 0 ? dofp[0][k] : dofp[1][k]; }
-            dsc = s == 0 ? dscp[0] : dscp[1];
-        } else {
-            attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
-            dsc = load_do_delta(qt, dof);
+            for (int k = 0; k < G::NKG; ++k) {
+                const T* a = (const T*)&dof[k];
+                const T* b = (const T*)&of[k];
+#pragma unroll
+                for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
+            }
         }
+        const float dsc = cross4_sum(delta) * p.scale;
         if (g == 0 && vq) st_d[qrow] = dsc;
         const float lse = st_l[vq ? qrow : 0];
         const uint32_t ibase = (hbase + (uint32_t)qrow) * T4;
         f32x4 qacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) qacc[dt] = f32x4{0, 0, 0, 0};
-        [[maybe_unused]] f32x4 san[2], dpn[2];                   // PIPE: the next group's scores, in flight
-        if constexpr (PIPE) {
-#pragma unroll
-            for (int u = 0; u < TPG; ++u) { san[u] = attn::tile_dot<T>(bufA, u, qf, i, g); dpn[u] = attn::tile_dot<T>(bufB, u, dof, i, g); }
-        }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int sb_i = gi;
             f32x4 ds[2];
-            [[maybe_unused]] f32x4 sac[2], dpc[2];
-            [[maybe_unused]] u32x4 ktf[4];
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int u = 0; u < TPG; ++u) { sac[u] = san[u]; dpc[u] = dpn[u]; }
-                if (gi + 1 < NG) {
-#pragma unroll
-                    for (int u = 0; u < TPG; ++u) { san[u] = attn::tile_dot<T>(bufA, (gi + 1) * TPG + u, qf, i, g); dpn[u] = attn::tile_dot<T>(bufB, (gi + 1) * TPG + u, dof, i, g); }
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) ktf[dt] = attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane);
-            }
 #pragma unroll
             for (int u = 0; u < TPG; ++u) {
                 const int t = gi * TPG + u;
-                const f32x4 sa = PIPE ? sac[u] : attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
-                f32x4 dp = PIPE ? dpc[u] : attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
+                const f32x4 sa = attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
+                f32x4 dp = attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
                 if constexpr (DROP) {      // keep bits are hashed once, here; phase B reads them back from LDS
                     const uint32_t m = drop_select4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp);
                     if constexpr (USE_MASK) st_m[(4 * t + g) * TP + qrow] = (unsigned char)m;
@@ -313,7 +267,7 @@ __global__ void __launch_bounds__(QL ? 64 * KT : 512, MINB) attn_bwd_kernel(cons
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // dQ^T[d][query] += K^T[d][keys] * dS^T[keys][query]
-                qacc[dt] = mma16<T>(PIPE ? ktf[dt] : attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, qacc[dt]);
+                qacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, qacc[dt]);
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
@@ -324,64 +278,30 @@ __global__ void __launch_bounds__(QL ? 64 * KT : 512, MINB) attn_bwd_kernel(cons
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase B
-    [[maybe_unused]] u32x4 vfp[NPRE][G::NKG];
-    if constexpr (QL) {
-        // this wave's V rows of phase B from the V tile, before the dO tile takes its place (rows beyond T are zero in the tile)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int k = 0; k < G::NKG; ++k) vfp[s][k] = lds16(bufB + attn::toff<T>(min((wave + s * nw) * 16 + i, TP - 1), k * 4 + g));
-        __syncthreads();
-        attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
-    } else {
-        attn::load_tile<T>(bufA, qbase, ldq, p.T, TP);
-        attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
-    }
+    attn::load_tile<T>(bufA, qbase, ldq, p.T, TP);
+    attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
     __syncthreads();
-    const unsigned char* const tQ = QL ? bufC : bufA;        // the Q tile
-    for (int s = 0, kt = wave; kt * 16 < p.T && !(ABL & 1); ++s, kt += nw) {
+    for (int kt = wave; kt * 16 < p.T && !(ABL & 1); kt += nw) {
         const int krow = kt * 16 + i;
         const bool vk = !PAD || krow < p.T;
         u32x4 kf[G::NKG], vf[G::NKG];
-        if constexpr (QL) {
-#pragma unroll
-            for (int k = 0; k < G::NKG; ++k) { kf[k] = lds16(bufA + attn::toff<T>(krow, k * 4 + g)); vf[k] = s == 0 ? vfp[0][k] : vfp[1][k]; }
-        } else {
-            attn::load_row_frags<T>(kf, kbase, ldq, krow, vk, g);
-            attn::load_row_frags<T>(vf, vbase, ldq, krow, vk, g);
-        }
+        attn::load_row_frags<T>(kf, kbase, ldq, krow, vk, g);
+        attn::load_row_frags<T>(vf, vbase, ldq, krow, vk, g);
         f32x4 kacc[4], vacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
         // this key's keep bits of queries 16t + 4g + r: byte r of word [krow / 4][16t + 4g], bit krow % 4
         [[maybe_unused]] const unsigned char* const mrow = st_m + (krow >> 2) * TP + 4 * g;
         [[maybe_unused]] const int mbit = krow & 3;
-        [[maybe_unused]] f32x4 san[2], dan[2];
-        if constexpr (PIPE) {
-#pragma unroll
-            for (int u = 0; u < TPG; ++u) { san[u] = attn::tile_dot<T>(tQ, u, kf, i, g); dan[u] = attn::tile_dot<T>(bufB, u, vf, i, g); }
-        }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int sb_i = gi;
             f32x4 pd[2], ds[2];
-            [[maybe_unused]] f32x4 sac[2], dac[2];
-            [[maybe_unused]] u32x4 dtf[4], qtf[4];
-            if constexpr (PIPE) {
-#pragma unroll
-                for (int u = 0; u < TPG; ++u) { sac[u] = san[u]; dac[u] = dan[u]; }
-                if (gi + 1 < NG) {
-#pragma unroll
-                    for (int u = 0; u < TPG; ++u) { san[u] = attn::tile_dot<T>(tQ, (gi + 1) * TPG + u, kf, i, g); dan[u] = attn::tile_dot<T>(bufB, (gi + 1) * TPG + u, vf, i, g); }
-                }
-#pragma unroll
-                for (int dt = 0; dt < 4; ++dt) { dtf[dt] = attn::tile_tr<T>(bufB, gi * KG, dt * 16, lane); qtf[dt] = attn::tile_tr<T>(tQ, gi * KG, dt * 16, lane); }
-            }
 #pragma unroll
             for (int u = 0; u < TPG; ++u) {
                 const int t = gi * TPG + u;
-                const f32x4 sa = PIPE ? sac[u] : attn::tile_dot<T>(tQ, t, kf, i, g);      // S[query 16t+4g+r][key krow]
-                const f32x4 da = PIPE ? dac[u] : attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
+                const f32x4 sa = attn::tile_dot<T>(bufA, t, kf, i, g);    // S[query 16t+4g+r][key krow]
+                const f32x4 da = attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
                 const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
                 const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
                 [[maybe_unused]] f32x4 keep4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
@@ -407,8 +327,8 @@ __global__ void __launch_bounds__(QL ? 64 * KT : 512, MINB) attn_bwd_kernel(cons
             const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                vacc[dt] = mma16<T>(PIPE ? dtf[dt] : attn::tile_tr<T>(bufB, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
-                kacc[dt] = mma16<T>(PIPE ? qtf[dt] : attn::tile_tr<T>(tQ, gi * KG, dt * 16, lane), sb, kacc[dt]);    // dK^T += Q^T dS
+                vacc[dt] = mma16<T>(attn::tile_tr<T>(bufB, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
+                kacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
             }
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }

@@ -45,7 +45,7 @@ struct ParamInfo { std::string name; int64_t numel, offset; };
 // The ctypes loader forwards GE2E_<NAME> environment variables here only when GE2E_DEV_SWITCHES=1 (tools/ab.sh, tools/switch_test.sh).
 enum Opt {
     O_NO_OVERLAP, O_NO_WS_GEMM, O_NO_KL_GEMM, O_NO_LNFUSE, O_NO_SK_GEMM, O_NO_FFN_CHAIN, O_FFN_WV, O_NO_FFN_CHAIN_BWD, O_NO_WGRAD_KS,
-    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE, O_NO_ATTN_BWD_QL,
+    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE,
     O_DEBUG_BWD_STOP, O_DEBUG_SIDE_DELAY_US, O_COUNT
 };
 struct OptDef { const char* name; int def; };
@@ -65,7 +65,6 @@ constexpr OptDef OPT_DEFS[O_COUNT] = {
     {"no_maskbits", 0},         // dF reads the stored hidden as its mask
     {"no_colsum_end", 0},       // norm2 column sums on the weight-gradient stream
     {"no_prenet_fuse", 0},      // prenet backward as recompute GEMM + weight-gradient launch
-    {"no_attn_bwd_ql", 0},      // attention backward at 129-160 frames without the LDS-resident Q tile / prefetched dO rows (round 3's form)
     {"debug_bwd_stop", -1},     // >= 0: backward returns after k layers (parity tests read that layer's scratch through ge2e_debug_tap)
     {"debug_side_delay_us", 0}, // tests: hold the weight-gradient stream back after every fork
 };
@@ -653,17 +652,9 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
         if (nw >= 5 && 3 * smem <= (size_t)160 * 1024) smem = (size_t)160 * 1024 / 3 + 1024;
         // a scheduling barrier after every tile group (32 keys / queries): 112-120 registers, three blocks per CU fit; spaced wider the
         // compiler hoists fragment loads (130 registers at 5 groups; 247-256 + spills when a loop never meets a barrier)
-        if constexpr (sizeof(T) == 2 && KT == 5) {
-            // QL form (attention.cuh): Q tile LDS-resident beside K and V, dO / O rows prefetched, phase B's K / V rows from LDS: 6 instead of 8
-            // activation tiles fetched per launch.  Still two blocks per CU at 129-160 frames (69 KB); at shorter lengths the third / fourth
-            // resident block is worth more than the saved fetches (128 frames alone: 231 vs 174 us), so only this length class takes it.
-            if (nw == KT && !opt(O_NO_ATTN_BWD_QL)) {
-                const size_t sq = 3 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (DROP ? (size_t)TP * (TP / 4) : 0);
-                auto kq = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, true>;
-                GE2E_LAUNCH(h, kq, grid, block, sq, st, a);
-                return 0;
-            }
-        }
+        // (Round 4, measured and not kept -- profiles/r04_ab_log.txt, commit c4d4096: the Q tile LDS-resident beside K and V with prefetched dO / O
+        // rows, 6 instead of 8 activation tiles fetched: 287 vs 294 us alone, 3.527 vs 3.525-3.549 ms in the step; the score MFMAs of the next
+        // group issued by hand ahead of the vector work: 354-386 us; a kernel that evaluates every score once, tools/attention_bwd1.cuh: 396-409 us.)
         auto kern = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 2>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     }

@@ -1,6 +1,6 @@
 // Attention backward variants at the headline shape, same inputs (a real forward's o / lse), outputs compared, each timed alone on the chip
-// (development tool): attn_bwd_kernel as round 3 shipped it, its QL form (Q tile LDS-resident, dO / O rows prefetched: round 4), and
-// tools/attention_bwd1.cuh (every score evaluated once; measured and NOT shipped: profiles/r04_ab_log.txt).
+// (development tool): attn_bwd_kernel as shipped and tools/attention_bwd1.cuh (every score evaluated once; measured and NOT shipped:
+// profiles/r04_ab_log.txt; the QL / PIPE variants of attn_bwd_kernel measured beside it live in commit c4d4096).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I speaker_embedding_torch_amd/csrc -I tools tools/attn_bwd_bench.hip -o tools/attn_bwd_bench
 //   tools/attn_bwd_bench [T] [n]       (T <= 288; default 160 frames, 960 utterances)
 #include <cmath>
@@ -44,42 +44,6 @@ template <int KT, bool PAD, bool DROP> void run(AttnArgs a, int n, bf16_t* dq_ol
     CHECK(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
     a.dqkv = dq_old;
     const float t_old = time_kernel([&]() { hipLaunchKernelGGL(kb, dim3(n * 4), dim3(64 * nw), sb, 0, a); });
-    if constexpr (KT <= 5) {       // QL form: three tiles + keep bytes; scheduling-barrier spacing 1 / 2 / 5 key groups
-        const size_t sq = 3 * (size_t)TP * G::LD + 2 * TP * 4 + (DROP ? TP * (TP / 4) : 0);
-        auto time_ql = [&](auto kq, const char* tag) {
-            CHECK(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sq));
-            int occq = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occq, (const void*)kq, 64 * KT, sq));
-            CHECK(hipMemset(dq_new, 0xFF, R * 768 * 2));
-            a.dqkv = dq_new;
-            const float t_ql = time_kernel([&]() { hipLaunchKernelGGL(kq, dim3(n * 4), dim3(64 * KT), sq, 0, a); });
-            CHECK(hipDeviceSynchronize());
-            std::vector<unsigned short> ho(R * 768), hn(R * 768);
-            AttnArgs s = a; s.dqkv = dq_old;
-            hipLaunchKernelGGL(kb, dim3(n * 4), dim3(64 * nw), sb, 0, s);
-            CHECK(hipDeviceSynchronize());
-            CHECK(hipMemcpy(ho.data(), dq_old, R * 768 * 2, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hn.data(), dq_new, R * 768 * 2, hipMemcpyDeviceToHost));
-            size_t diff = 0;
-            for (size_t e = 0; e < R * 768; ++e) diff += ho[e] != hn[e];
-            printf("T %3d KT %d pad %d drop %d | old %7.1f us | %s %7.1f us (%zu B LDS, %d blocks/CU), %zu of %zu output elements differ from old\n", a.T, KT, (int)PAD, (int)DROP, t_old, tag, t_ql, sq, occq, diff, R * 768);
-        };
-        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, true>, "QL sbe1");
-        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3, true>, "QL sbe2");
-        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 5, 0, 3, true>, "QL sbe5");
-        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, true, true>, "QL pipe sbe1");
-        time_ql(attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3, true, true>, "QL pipe sbe2");
-        CHECK(hipMemset(dq_new, 0xFF, R * 768 * 2));
-    }
-    {
-        auto k2 = attn_bwd_kernel<T, KT, PAD, DROP, 2, 0, 3>; auto k5 = attn_bwd_kernel<T, KT, PAD, DROP, 5, 0, 3>;
-        CHECK(hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb)); CHECK(hipFuncSetAttribute((const void*)k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
-        AttnArgs s = a; s.dqkv = dq_old;
-        const float t2 = time_kernel([&]() { hipLaunchKernelGGL(k2, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
-        const float t5 = time_kernel([&]() { hipLaunchKernelGGL(k5, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
-        auto kp = attn_bwd_kernel<T, KT, PAD, DROP, 1, 0, 3, false, true>;
-        CHECK(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sb));
-        const float tp = time_kernel([&]() { hipLaunchKernelGGL(kp, dim3(n * 4), dim3(64 * nw), sb, 0, s); });
-        printf("        old form with scheduling barriers every 2 / 5 groups: %7.1f / %7.1f us; pipelined by hand (sbe 1): %7.1f us\n", t2, t5, tp);
-    }
     using PL = attn1::Plan<KT>;
     a.dqkv = dq_new;
     auto k1 = attn_bwd1_kernel<T, KT, PAD, DROP>;
@@ -96,7 +60,7 @@ template <int KT, bool PAD, bool DROP> void run(AttnArgs a, int n, bf16_t* dq_ol
     CHECK(hipMemcpy(ho.data(), dq_old, R * 768 * 2, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hn.data(), dq_new, R * 768 * 2, hipMemcpyDeviceToHost));
     const char* nm[3] = {"dQ", "dK", "dV"};
     (void)t_a; (void)t_b; (void)t_c; (void)t_d;
-    printf("        single-evaluation kernel %7.1f us (QP %d, %d B LDS, %d blocks/CU) |", t_new, PL::QP, PL::SMEM, occ);
+    printf("T %3d KT %d pad %d drop %d | shipped %7.1f us | single-evaluation kernel %7.1f us (QP %d, %d B LDS, %d blocks/CU) |", a.T, KT, (int)PAD, (int)DROP, t_old, t_new, PL::QP, PL::SMEM, occ);
     for (int part = 0; part < 3; ++part) {
         double num = 0, den = 0, mx = 0;
         for (size_t r = 0; r < R; ++r)
