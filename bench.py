@@ -36,8 +36,8 @@ from speaker_embedding_torch_amd.Arg_Parser import Load_Hyper_Parameters  # noqa
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss  # noqa: E402
 from speaker_embedding_torch_amd.Optim import FusedClipAdamW, GradScaler  # noqa: E402
 
-PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
-DTYPE_NAME = {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}
+PEAK = {"bf16": 2500.0, "fp16": 2500.0, "fp32": 157.3, "fp32x3": 2500.0 / 3.0}            # dense MFMA TFLOP/s, MI355X_MICROARCH.md chip table
+DTYPE_NAME = {"bf16": "bf16", "fp16": "f16", "fp32": "f32", "fp32x3": "f32 storage, split-bf16 (bf16x3) products"}
 HBM_PEAK_GBS = 8000.0                             # HBM3E spec peak (6.3 TB/s is what a copy kernel reaches)
 ROOFLINE_CLASSES = {"gemm": _lib.K_GEMM, "gemm_ln": _lib.K_GEMM_LN, "wgrad": _lib.K_WGRAD,
                     "attn_fwd": _lib.K_ATTN_FWD, "attn_bwd": _lib.K_ATTN_BWD, "ffn": _lib.K_FFN}
@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32", "fp32x3"])
     ap.add_argument("--speakers", type=int, default=None)
     ap.add_argument("--utts", type=int, default=None)
     ap.add_argument("--frames", type=int, default=160)

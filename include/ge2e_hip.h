@@ -39,8 +39,12 @@ enum {
 /* Arithmetic modes.  F32: fp32 MFMA (exact fma chains; the parity path, reference `Use_Mixed_Precision: false`).
  * BF16 / F16: activations and activation gradients stored in 16 bits, fp32 accumulation, fp32 master weights, fp32
  * parameter gradients.  F16 is what the reference's own mixed precision is (torch.cuda.amp.autocast + GradScaler,
- * Train.py:134,145,153-162): its gradients need the loss scaling of ge2e_clip_adamw_step_scaled; BF16 does not. */
-enum { GE2E_PREC_F32 = 0, GE2E_PREC_BF16 = 1, GE2E_PREC_F16 = 2 };
+ * Train.py:134,145,153-162): its gradients need the loss scaling of ge2e_clip_adamw_step_scaled; BF16 does not.
+ * F32X3 (round 4): fp32 STORAGE everywhere, exactly the F32 mode's tensors and workspace, with the projection GEMMs and weight gradients
+ * computed on the bf16 matrix pipe from operands split into bf16 hi + lo halves (three products per term, fp32 accumulation: ~2^-17
+ * relative per product instead of 2^-24); attention, LayerNorm, tail and loss stay exact fp32.  d-vectors stay within the 1e-4 of
+ * north_star at a multiple of the F32 mode's speed. */
+enum { GE2E_PREC_F32 = 0, GE2E_PREC_BF16 = 1, GE2E_PREC_F16 = 2, GE2E_PREC_F32X3 = 3 };
 
 /* Mirrors the `Sound.Mel_Dim` / `GE2E.*` block of Hyper_Parameters.yaml:1-18 plus the arithmetic mode. */
 typedef struct ge2e_config {
@@ -53,7 +57,7 @@ typedef struct ge2e_config {
     float pe_dropout;        /* GE2E.Positional_Encoding.Dropout_Rate                */
     float tf_dropout;        /* GE2E.Transformer.Dropout_Rate                        */
     float ln_eps;            /* torch LayerNorm default 1e-5                         */
-    int32_t precision;       /* GE2E_PREC_F32 / GE2E_PREC_BF16 / GE2E_PREC_F16 */
+    int32_t precision;       /* GE2E_PREC_F32 / _BF16 / _F16 / _F32X3 */
 } ge2e_config;
 
 typedef struct ge2e_handle_s* ge2e_handle;

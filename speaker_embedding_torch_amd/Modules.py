@@ -194,7 +194,8 @@ def default_precision(hp):
 class GE2E(torch.nn.Module):
     """Speaker encoder of reference Modules.py:5-59 on the HIP path.
 
-    `precision`: 'fp32' (fp32 MFMA; d-vectors within 1e-4 of the reference CPU path), 'bf16' or 'fp16' (16-bit
+    `precision`: 'fp32' (fp32 MFMA; d-vectors within 1e-4 of the reference CPU path), 'fp32x3' (fp32 storage, the projection
+    products as three bf16 MFMAs on split operands: still within 1e-4, a multiple of the fp32 speed), 'bf16' or 'fp16' (16-bit
     storage / fp32 accumulate; fp16 is the reference's own mixed precision and wants the GradScaler of Optim.py).
     Default follows `hp.Use_Mixed_Precision` like Train.py:134,145: false -> 'fp32'; true -> the optional key
     `hp.Mixed_Precision_Dtype` ('bf16' | 'fp16'), 'fp16' when the key is absent (what autocast means in the reference).
@@ -213,7 +214,7 @@ class GE2E(torch.nn.Module):
         if precision is None:
             precision = default_precision(self.hp)
         if precision not in _lib.PRECISIONS:
-            raise ValueError("precision must be 'fp32', 'bf16' or 'fp16'")
+            raise ValueError("precision must be 'fp32', 'fp32x3', 'bf16' or 'fp16'")
         self.precision = precision
         self.seed = int(seed)
         self._step = 0
@@ -268,7 +269,7 @@ class GE2E(torch.nn.Module):
         (`dtype=torch.float32` for the fp32 side tables "rstd1.<l>", "rstd2.<l>", "lse.<l>")."""
         off, size = self._handle().debug_tap(name, n, t, train)
         ws = self._ws[(bool(train), self.precision)]
-        dt = dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[self.precision]
+        dt = dtype or {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp32x3": torch.float32}[self.precision]
         return ws[off:off + size].view(dt)
 
     # -- reference API -------------------------------------------------------------------------

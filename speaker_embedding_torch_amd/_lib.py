@@ -12,8 +12,8 @@ _lib = None
 
 BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64)
 
-PREC_F32, PREC_BF16, PREC_F16 = 0, 1, 2
-PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16}
+PREC_F32, PREC_BF16, PREC_F16, PREC_F32X3 = 0, 1, 2, 3
+PRECISIONS = {"fp32": PREC_F32, "bf16": PREC_BF16, "fp16": PREC_F16, "fp32x3": PREC_F32X3}
 ABI_VERSION = 4
 K_GEMM, K_GEMM_LN, K_WGRAD, K_ATTN_FWD, K_ATTN_BWD, K_LN_BWD, K_FFN = 1, 2, 4, 8, 16, 32, 64
 FWD_PREPARED = 2       # ge2e_encoder_forward's `train` argument: eval forward, weight copies already in the workspace

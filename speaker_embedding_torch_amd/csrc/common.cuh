@@ -62,6 +62,29 @@ template <> __device__ __forceinline__ f32x4 mma16<f16_t>(u32x4 a, u32x4 b, f32x
 }
 
 // ---------------------------------------------------------------------------------------------
+// "fp32x3": fp32 STORAGE, products on the bf16 matrix pipe (round 4).  x = hi + lo with hi = bf16(x) and lo = bf16(x - hi) (the difference is
+// exact in fp32), so a.b = ah.bh + ah.bl + al.bh up to the dropped al.bl term: ~2^-17 relative per product (8 + 8 mantissa bits per
+// operand) where an fp32 fma chain has 2^-24 -- three v_mfma_f32_16x16x32_bf16 (48 matrix-pipe cycles per 16 x 16 x 32) instead of eight
+// v_mfma_f32_16x16x4_f32 (256).  The split happens ONCE per element and tile, on the way from global memory into the LDS stage (gemm.cuh),
+// never per MFMA use; accumulation stays fp32.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_bf16x3(u32x4 v, u32x2& hi, u32x2& lo) {
+    const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+    hi.x = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){x0, x1}, __attribute__((ext_vector_type(2))) __bf16));
+    hi.y = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){x2, x3}, __attribute__((ext_vector_type(2))) __bf16));
+    const float r0 = x0 - __uint_as_float(hi.x << 16), r1 = x1 - __uint_as_float(hi.x & 0xFFFF0000u);
+    const float r2 = x2 - __uint_as_float(hi.y << 16), r3 = x3 - __uint_as_float(hi.y & 0xFFFF0000u);
+    lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r0, r1}, __attribute__((ext_vector_type(2))) __bf16));
+    lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r2, r3}, __attribute__((ext_vector_type(2))) __bf16));
+}
+// C += A.B from the split halves (small terms first)
+__device__ __forceinline__ f32x4 mma16_x3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
+    c = mma16<bf16_t>(al, bh, c);
+    c = mma16<bf16_t>(ah, bl, c);
+    return mma16<bf16_t>(ah, bh, c);
+}
+
+// ---------------------------------------------------------------------------------------------
 // scalar conversions
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float v) { return v; }

@@ -180,7 +180,7 @@ struct Layout {
 Layout build_layout(const ge2e_config& c, int n, int t, int train, int samples_max = 1) {
     (void)samples_max;
     Layout L;
-    L.esz = c.precision == GE2E_PREC_F32 ? 4 : 2;
+    L.esz = (c.precision == GE2E_PREC_F32 || c.precision == GE2E_PREC_F32X3) ? 4 : 2;
     L.KP = 128;                  // mel_dim <= 128, padded to one 128-column operand tile
     L.R = n * t;
     size_t off = 0;
@@ -330,14 +330,14 @@ inline int debug_side_delay_us() { return std::max(0, std::min(opt(O_DEBUG_SIDE_
         if (el != hipSuccess) return fail_hip(h, el, #kern);                                                \
     } while (0)
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2>
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2, bool X3 = false>
 int launch_gemm(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     constexpr int BK = 128 / (int)sizeof(T);
     if (a.K % BK != 0 || a.N % BN != 0 || a.M <= 0)
         return fail(h, GE2E_EUNSUPPORTED, "gemm: N must be a multiple of the tile and K of the k-step");
     const int grid = ((a.M + BM - 1) / BM) * (a.N / BN);
     const size_t smem = std::max<size_t>(NBUF * (size_t)(BM + BN) * 128, EPI == EPI_LN ? (size_t)BM * (BN + 4) * 4 : (size_t)BM * (BN * sizeof(T) + 16));
-    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD, NBUF>;
+    auto kern = gemm_nt_kernel<T, BM, BN, WM, WN, EPI, ALOAD, NBUF, (X3 && sizeof(T) == 4)>;
     constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_PRENET_BWD);
     const double kk = a.K;
     // algorithmic HBM bytes of one launch: activations in (fp32 mel for the prenet) + weights + tile out (+ tile in)
@@ -393,7 +393,7 @@ int launch_gemm_ws_lnbwd(ge2e_handle h, hipStream_t st, const GemmArgs& a, const
     return 0;
 }
 
-template <typename T, int EPI, int ALOAD = ALOAD_ROW>
+template <typename T, int EPI, int ALOAD = ALOAD_ROW, bool X3 = false>
 int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI>() && ALOAD == ALOAD_ROW) {
         if (ws_shape(a)) return launch_gemm_ws<T, EPI>(h, st, a);
@@ -401,7 +401,7 @@ int gemm128(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     // the VALU-heavy ReLU + dropout epilogue gains from a third resident block (single LDS stage: 35 KB), measured
     // 179 -> 144 us for FFN1; the other epilogues measure the same either way and keep the one-barrier double buffer
     constexpr int NBUF = (EPI == EPI_BIAS_RELU_DROP) ? 1 : 2;
-    return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD, NBUF>(h, st, a);
+    return launch_gemm<T, 128, 128, 64, 64, EPI, ALOAD, NBUF, X3>(h, st, a);
 }
 // K = 1024 products on the last layer's compact rows: split-K over 64-row pieces + a reduce / epilogue launch (gemm_sk.cuh).  part: [SK_KS][M][256] fp32.
 inline bool gemm_sk_on() { return !opt(O_NO_SK_GEMM); }
@@ -426,7 +426,7 @@ bool gemm_sk_shape(const GemmArgs& a, size_t skpart) {
     return sizeof(T) == 2 && gemm_sk_on() && skpart != (size_t)-1 && a.N == 256 && a.K % (32 * SK_KS) == 0 && a.K >= 512 && a.M > 0 && a.M <= SK_MAX_M &&
            a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 4 == 0 && a.ldr % 4 == 0;
 }
-template <typename T>
+template <typename T, bool X3 = false>
 int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     if constexpr (ws_epilogue<T, EPI_LN>()) {
         if (ws_shape(a)) return launch_gemm_ws<T, EPI_LN>(h, st, a);
@@ -447,7 +447,7 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
             return 0;
         }
     }
-    return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW>(h, st, a);
+    return launch_gemm<T, 64, 256, 32, 128, EPI_LN, ALOAD_ROW, 2, X3>(h, st, a);
 }
 
 // FFN1 -> ReLU -> dropout -> FFN2 -> dropout -> residual -> LayerNorm in one launch (ffn.cuh): 16-bit modes, full-height layers.
@@ -521,7 +521,7 @@ inline bool ffn_chain_bwd_on() { return !opt(O_NO_FFN_CHAIN_BWD); }
 // 256 x 256-tile split-K weight gradient (wgrad_ks.cuh) for the wide 16-bit products; everything else (and the rows beyond the
 // last multiple of 32) on the 128 x 128 kernel below.
 inline bool wgrad_ks_on() { return !opt(O_NO_WGRAD_KS); }
-template <typename T, int XLOAD> int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a);
+template <typename T, int XLOAD, bool X3 = false> int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a);
 
 // reduce passes of the split-K products launched since the last flush (one slab each): flushed as ONE launch at the end of a layer
 struct WkPending {
@@ -541,7 +541,7 @@ int flush_wk_reduce(ge2e_handle h, hipStream_t st, WkPending& pend) {
     return 0;
 }
 
-template <typename T, int XLOAD>
+template <typename T, int XLOAD, bool X3 = false>
 int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullptr, WkPending* pend = nullptr) {
     if constexpr (sizeof(T) == 2) {
         const int tn = a.N / 256, tk = a.K / 256;
@@ -598,13 +598,14 @@ int launch_wgrad(ge2e_handle h, hipStream_t st, WgradArgs a, float* part = nullp
             return launch_wgrad_tiled<T, XLOAD>(h, st, tail);
         }
     }
-    return launch_wgrad_tiled<T, XLOAD>(h, st, a);
+    return launch_wgrad_tiled<T, XLOAD, X3>(h, st, a);
 }
 
-template <typename T, int XLOAD>
+template <typename T, int XLOAD, bool X3>
 int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a) {
+    constexpr bool X = X3 && sizeof(T) == 4;                 // fp32x3: two bf16 planes per operand tile, 16-bit row pitch
     constexpr int RS = 2 * Prec<T>::KG;
-    constexpr int LD = 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int LD = X ? 2 * (256 + 32) : 128 * (int)sizeof(T) + (sizeof(T) == 2 ? 32 : 16);
     if (a.N % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: N must be a multiple of 128");
     if (XLOAD == ALOAD_ROW && a.ldx % 128 != 0) return fail(h, GE2E_EUNSUPPORTED, "wgrad: the X operand must be stored in whole 128-column tiles");
     const int tn = a.N / 128, tk = (a.K + 127) / 128;
@@ -621,7 +622,7 @@ int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a) {
     splits = (a.R + rps - 1) / rps;
     a.rows_per_split = rps; a.tiles_n = tn; a.tiles_k = tk;
     const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
-    auto kern = wgrad_kernel<T, XLOAD>;
+    auto kern = wgrad_kernel<T, XLOAD, 3, 2, X>;
     ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * a.R * a.N * a.K, (double)a.R * (a.N + a.K) * sizeof(T) + 4.0 * a.N * a.K);
     GE2E_LAUNCH(h, kern, dim3(tn * tk * splits), dim3(256), smem, st, a);
     return 0;
@@ -823,7 +824,7 @@ struct SideCtx {
     }
 };
 
-template <typename T>
+template <typename T, bool X3 = false>
 int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, int n, int t, int samples,
                  const float* const* P, const float* pe, float* out_emb, unsigned char* ws, const Layout& L,
                  bool train, uint64_t seed, uint64_t step, bool prepared = false) {
@@ -876,7 +877,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         a.drop = make_drop(train, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.alpha = P[P_ALPHA]; a.T = t; a.mel = c.mel_dim;
         a.relu_bits = train ? ws + L.pbits : nullptr;
-        CK((gemm128<T, EPI_PRENET>(h, st, a)));
+        CK((gemm128<T, EPI_PRENET, ALOAD_ROW, X3>(h, st, a)));
     }
     for (int l = 0; l < c.layers; ++l) {
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);
@@ -890,12 +891,12 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             GemmArgs a{};
             a.A = hin; a.lda = d; a.W = ws + L.w_in[l]; a.ldw = d; a.C = ws + L.qkv[l]; a.ldc = 3 * d;
             a.M = R; a.N = 3 * d; a.K = d; a.bias = P[lp(l, L_IN_B)];
-            CK((gemm128<T, EPI_BIAS>(h, st, a)));
+            CK((gemm128<T, EPI_BIAS, ALOAD_ROW, X3>(h, st, a)));
         } else {
             GemmArgs q{};   // q of frame 0: rows n * T of hin -> compact rows
             q.A = hin; q.lda = d * t; q.W = ws + L.w_in[l]; q.ldw = d; q.C = ws + L.lq0; q.ldc = d;
             q.M = n; q.N = d; q.K = d; q.bias = P[lp(l, L_IN_B)];
-            CK((gemm128<T, EPI_BIAS>(h, st, q)));
+            CK((gemm128<T, EPI_BIAS, ALOAD_ROW, X3>(h, st, q)));
             // one query per (utterance, head): scores and context straight from the layer input, K and V never exist (attn_last.cuh)
             AttnLastArgs a = attn_last_args(c, L, ws, P, l, t, hin, train, make_drop(train, c.tf_dropout, seed, step, site_attn(l)));
             a.o0 = ws + L.o[l];
@@ -918,7 +919,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)]; a.eps = c.ln_eps;
             a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.drow_mul = rmul;
-            CK(gemm_ln<T>(h, st, a));
+            CK((gemm_ln<T, X3>(h, st, a)));
         }
         if (sizeof(T) == 2 && !last && c.ffn == FFN_F && d == 256 && ffn_chain_on()) {
             // linear1 + ReLU + dropout + linear2 + dropout2 + residual + norm2, the hidden on chip (written once in train mode)
@@ -938,7 +939,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.A = ws + L.h1[l]; a.lda = d; a.W = ws + L.w_l1[l]; a.ldw = d; a.C = ws + L.f[l]; a.ldc = c.ffn;
             a.M = Rl; a.N = c.ffn; a.K = d; a.bias = P[lp(l, L_L1_B)];
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_ffh(l)); a.drow_mul = rmul;
-            CK((gemm128<T, EPI_BIAS_RELU_DROP>(h, st, a)));
+            CK((gemm128<T, EPI_BIAS_RELU_DROP, ALOAD_ROW, X3>(h, st, a)));
         }
         {   // linear2 + dropout2 + residual + norm2
             GemmArgs a{};
@@ -948,7 +949,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.rstd = train ? (float*)(ws + L.rstd2[l]) : nullptr;
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_ff(l)); a.drow_mul = rmul;
             if (last && gemm_sk_shape<T>(a, L.skpart)) CK((launch_gemm_sk<T, true>(h, st, a, (float*)(ws + L.skpart))));
-            else CK(gemm_ln<T>(h, st, a));
+            else CK((gemm_ln<T, X3>(h, st, a)));
         }
     }
     {   // final LN at t = 0 -> slice mean -> projection -> L2 normalise
@@ -966,24 +967,24 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
 }
 
 inline bool maskbits_on() { return !opt(O_NO_MASKBITS); }
-template <typename T>
+template <typename T, bool X3>
 int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
                   uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user);
 
-template <typename T>
+template <typename T, bool X3 = false>
 int backward_impl(ge2e_handle h, hipStream_t st, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
                   uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user) {
     SideCtx sc(h, st);
-    const int rc = backward_body<T>(h, st, sc, mel, n, t, samples, P, d_emb, grads, ws, L, seed, step, cb, user);
+    const int rc = backward_body<T, X3>(h, st, sc, mel, n, t, samples, P, d_emb, grads, ws, L, seed, step, cb, user);
     sc.join();                                           // also when a launch failed half-way: nothing is left running on the side stream
     if (rc) return rc;
     if (sc.err) return fail(h, GE2E_EINVAL, "side-stream event fencing failed");
     return 0;
 }
 
-template <typename T>
+template <typename T, bool X3>
 int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, int n, int t, int samples,
                   const float* const* P, const float* d_emb, float* grads, unsigned char* ws, const Layout& L,
                   uint64_t seed, uint64_t step, ge2e_bucket_cb cb, void* user) {
@@ -1106,7 +1107,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
                 a.R = ws + L.fbits[l]; a.ldr = c.ffn / 8;
                 if constexpr (sizeof(T) == 2) CK((launch_gemm_ws<T, EPI_MASKBITS>(h, st, a)));
             } else
-            CK((gemm128<T, EPI_MASK>(h, st, a)));
+            CK((gemm128<T, EPI_MASK, ALOAD_ROW, X3>(h, st, a)));
         }
         }
         sc.fork();
@@ -1114,14 +1115,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
             a.R = Rl; a.N = d; a.K = c.ffn; a.blocks = wk_blocks(0);
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
+            CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, a, wpart, &pend)));
             if (!last) g_set1[bs] = sc.mark();
         }
         {
             WgradArgs a{};
             a.Y = b_dF; a.ldy = c.ffn; a.X = ws + L.h1[l]; a.ldx = d; a.dW = G(lp(l, L_L1_W)); a.ldw = d; a.db = G(lp(l, L_L1_B));
             a.R = Rl; a.N = c.ffn; a.K = d; a.blocks = wk_blocks(1);
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
+            CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, a, wpart, &pend)));
             if (!last) g_dF[bs] = sc.mark();
         }
         if (!chain_bwd) {   // dH1 = dPre2 + dF W1
@@ -1129,7 +1130,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.A = b_dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = b_dHb; a.ldc = d;
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
             if (last && gemm_sk_shape<T>(a, L.skpart)) CK((launch_gemm_sk<T, false>(h, st, a, (float*)(ws + L.skpart))));
-            else CK((gemm128<T, EPI_ADD>(h, st, a)));
+            else CK((gemm128<T, EPI_ADD, ALOAD_ROW, X3>(h, st, a)));
         }
         if (!last) sc.wait(g_set2[bs]);
         gm = d_sa.thr ? b_dM2 : b_dP2;
@@ -1155,14 +1156,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             ProfScope ps(h, st, GE2E_K_LN_BWD, 12.0 * Rl * d, (double)Rl * d * L.esz * (d_sa.thr ? 4 : 3));
             GE2E_LAUNCH(h, kern, dim3(ln_grid), dim3(256), 0, st, a);
         }
-        CK((gemm128<T, EPI_NONE>(h, st, ado)));
+        CK((gemm128<T, EPI_NONE, ALOAD_ROW, X3>(h, st, ado)));
         }
         sc.fork();
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
             a.R = Rl; a.N = d; a.K = d; a.blocks = wk_blocks(2);
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, a, wpart, &pend)));
+            CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, a, wpart, &pend)));
             if (!last) g_set2[bs] = sc.mark();
         }
         sc.wait(g_dQKV[bq]);
@@ -1178,7 +1179,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs w{};
             w.Y = b_dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));
             w.R = R; w.N = 3 * d; w.K = d; w.blocks = wk_blocks(3);
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, w, wpart, &pend)));
+            CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, w, wpart, &pend)));
             CK(flush_wk_reduce(h, wst, pend));
             g_dQKV[bq] = sc.mark();
             GemmArgs g{};   // dH(layer input) = dPre1 + dQKV Win
@@ -1186,7 +1187,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             g.M = R; g.N = d; g.K = 3 * d; g.R = b_dP2; g.ldr = d;
             sc.wait(g_dH[l % L.nH]);
             if (uses_chain_bwd(l - 1) && !defer_colsum) sc.arm();
-            CK((gemm128<T, EPI_ADD>(h, st, g)));
+            CK((gemm128<T, EPI_ADD, ALOAD_ROW, X3>(h, st, g)));
             CK(colsum_below());
         } else {
             // one query per (utterance, head), K / V never materialised (attn_last.cuh): dL/d(layer input) of every frame -- the K / V
@@ -1212,7 +1213,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             WgradArgs wq{};   // q rows from frame 0 of every utterance
             wq.Y = ws + L.c_dQ0; wq.ldy = d; wq.X = hin; wq.ldx = d * t; wq.dW = G(lp(l, L_IN_W)); wq.ldw = d; wq.db = G(lp(l, L_IN_B));
             wq.R = n; wq.N = d; wq.K = d;
-            CK((launch_wgrad<T, ALOAD_ROW>(h, wst, wq)));
+            CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, wq)));
             CK(flush_wk_reduce(h, wst, pend));
             CK(colsum_below(true));
         }
@@ -1249,11 +1250,11 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         a.M = R; a.N = d; a.K = L.KP; a.bias = P[P_PRENET_B];
         a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.dalpha = G(P_ALPHA); a.T = t; a.mel = c.mel_dim;
-        CK((gemm128<T, EPI_PRENET_BWD>(h, st, a)));
+        CK((gemm128<T, EPI_PRENET_BWD, ALOAD_ROW, X3>(h, st, a)));
         WgradArgs w{};     // dWp[256][mel] from the packed rows; columns mel..127 of the tile are discarded (k < K)
         w.Y = dH0; w.ldy = d; w.X = ws + L.xt; w.ldx = L.KP; w.dW = G(P_PRENET_W); w.ldw = c.mel_dim; w.db = G(P_PRENET_B);
         w.R = R; w.N = d; w.K = c.mel_dim;
-        CK((launch_wgrad<T, ALOAD_ROW>(h, st, w)));                 // (no split-K scratch here: wpart belongs to the side stream)
+        CK((launch_wgrad<T, ALOAD_ROW, X3>(h, st, w)));                 // (no split-K scratch here: wpart belongs to the side stream)
         }
         if (cb) { sc.fork(); bucket(P_PRENET_W, P_ALPHA); }   // final behind the side stream, as the other buckets
         for (int q = 0; q < ndeferred; ++q) {
@@ -1303,7 +1304,7 @@ int ge2e_create(const ge2e_config* cfg, ge2e_handle* out) {
     if (cfg->emb != 256 || cfg->heads <= 0 || cfg->emb / cfg->heads != 64 || cfg->emb % cfg->heads != 0) return GE2E_EUNSUPPORTED;
     if (cfg->layers < 1 || cfg->layers > MAX_LAYERS || cfg->mel_dim < 1 || cfg->mel_dim > 128) return GE2E_EUNSUPPORTED;
     if (cfg->ffn % 128 != 0 || cfg->ffn < 128 || cfg->max_position < 1) return GE2E_EUNSUPPORTED;
-    if (cfg->precision != GE2E_PREC_F32 && cfg->precision != GE2E_PREC_BF16 && cfg->precision != GE2E_PREC_F16) return GE2E_EINVAL;
+    if (cfg->precision != GE2E_PREC_F32 && cfg->precision != GE2E_PREC_BF16 && cfg->precision != GE2E_PREC_F16 && cfg->precision != GE2E_PREC_F32X3) return GE2E_EINVAL;
     if (cfg->pe_dropout < 0.f || cfg->pe_dropout >= 1.f || cfg->tf_dropout < 0.f || cfg->tf_dropout >= 1.f) return GE2E_EINVAL;
     ge2e_handle h = new (std::nothrow) ge2e_handle_s();
     if (!h) return GE2E_EINVAL;
@@ -1375,6 +1376,8 @@ static int encoder_forward_any(ge2e_handle h, void* stream, const void* mel, boo
         return forward_impl<bf16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
     if (h->cfg.precision == GE2E_PREC_F16)
         return forward_impl<f16_t>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
+    if (h->cfg.precision == GE2E_PREC_F32X3)
+        return forward_impl<float, true>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
     return forward_impl<float>(h, st, mel, mel_f16, n_utts, frames, samples, params, pe, out_emb, ws, L, train != 0, seed, step, prepared);
 }
 
@@ -1413,6 +1416,8 @@ int ge2e_encoder_backward_cb(ge2e_handle h, void* stream, const float* mel, int 
         return backward_impl<bf16_t>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
     if (h->cfg.precision == GE2E_PREC_F16)
         return backward_impl<f16_t>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
+    if (h->cfg.precision == GE2E_PREC_F32X3)
+        return backward_impl<float, true>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
     return backward_impl<float>(h, st, mel, n_utts, frames, samples, params, d_emb, grads_flat, ws, L, seed, step, cb, user);
 }
 

@@ -33,8 +33,11 @@ struct GemmArgs {
     unsigned char* relu_bits;    // EPI_PRENET (train): [M][N / 8] bytes, bit c & 7 of byte c >> 3 = "pre-activation of column c > 0" (prenet_bwd.cuh reads it)
 };
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2>
+// X3 (T = float only): the "fp32x3" mode of common.cuh -- an LDS row holds the bf16 hi halves of its 32 k values in chunks 0-3 and the lo
+// halves in chunks 4-7 (same 128 bytes), split on the way in; a k-step is then ONE 16x16x32 slice and three MFMAs per tile.
+template <typename T, int BM, int BN, int WM, int WN, int EPI, int ALOAD, int NBUF = 2, bool X3 = false>
 __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
+    static_assert(!X3 || sizeof(T) == 4, "fp32x3 is a mode of fp32 storage");
     constexpr int BK = 128 / (int)sizeof(T);            // 128-byte LDS rows = two k-groups
     constexpr int WAVES_N = BN / WN;
     constexpr int MT = WM / 16, NT = WN / 16;
@@ -78,11 +81,23 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
             const int id = tid + 256 * q;
+            if constexpr (X3) {
+                u32x2 hi, lo;
+                split_bf16x3(ra[q], hi, lo);
+                *(u32x2*)(a + swz_off<128>(id >> 3, (id & 7) >> 1) + 8 * (id & 1)) = hi;
+                *(u32x2*)(a + swz_off<128>(id >> 3, 4 + ((id & 7) >> 1)) + 8 * (id & 1)) = lo;
+            } else
             *(u32x4*)(a + swz_off<128>(id >> 3, id & 7)) = ra[q];
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int id = tid + 256 * q;
+            if constexpr (X3) {
+                u32x2 hi, lo;
+                split_bf16x3(rb[q], hi, lo);
+                *(u32x2*)(b + swz_off<128>(id >> 3, (id & 7) >> 1) + 8 * (id & 1)) = hi;
+                *(u32x2*)(b + swz_off<128>(id >> 3, 4 + ((id & 7) >> 1)) + 8 * (id & 1)) = lo;
+            } else
             *(u32x4*)(b + swz_off<128>(id >> 3, id & 7)) = rb[q];
         }
     };
@@ -101,6 +116,21 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(const GemmArgs p) {
         if (ks + 1 < nk) load_stage(ks + 1);
         const unsigned char* a = As + buf * BM * 128;
         const unsigned char* b = Bs + buf * BN * 128;
+        if constexpr (X3) {
+            u32x4 ah[MT], al[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                ah[mt] = lds16(a + swz_off<128>(wm * WM + mt * 16 + i, g));
+                al[mt] = lds16(a + swz_off<128>(wm * WM + mt * 16 + i, 4 + g));
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 bh = lds16(b + swz_off<128>(wn * WN + nt * 16 + i, g));
+                const u32x4 bl = lds16(b + swz_off<128>(wn * WN + nt * 16 + i, 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = mma16_x3(bh, bl, ah[mt], al[mt], acc[mt][nt]);
+            }
+        } else
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
             u32x4 af[MT];
@@ -308,19 +338,24 @@ struct WgradArgs {
     int blocks;                 // host side: wgrad_ks blocks for this product (0 = the library's default share of the chip)
 };
 
-template <typename T, int XLOAD, int NS_ = 3, int KGS = 2>
+// X3 (T = float only): the "fp32x3" mode of common.cuh -- a stage is 32 rows = one 16x16x32 slice; every operand tile is kept as two bf16
+// planes (hi, lo) in the 16-bit layout (transposed reads with ds_read_b64_tr_b16), split on the way in; three MFMAs per tile and stage.
+template <typename T, int XLOAD, int NS_ = 3, int KGS = 2, bool X3 = false>
 __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
+    static_assert(!X3 || sizeof(T) == 4, "fp32x3 is a mode of fp32 storage");
     constexpr int KG = Prec<T>::KG;
     constexpr int RS = KGS * KG;                            // rows per stage
     constexpr int ROWB = 128 * (int)sizeof(T);              // 128 columns
     // row stride == 32 (mod 256) bytes: the 8 rows x 4 lanes x 8 B of one ds_read_b64_tr_b16 half-wave land on 64
     // distinct banks (a 16-byte pad leaves 2-way conflicts on every transposed read); fp32 scalar reads want +16
-    constexpr int LD = ROWB + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int LD = X3 ? 256 + 32 : ROWB + (sizeof(T) == 2 ? 32 : 16);
+    constexpr int PL = X3 ? 2 : 1;                          // planes per operand tile (X3: hi, lo)
     constexpr int CPR = ROWB / 16;                          // chunks per row
     constexpr int NCH = RS * CPR / 256;                     // chunks per thread (= 4)
+    static_assert(!X3 || RS == 32, "fp32x3: one 32-row slice per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Ys = smem;                         // [2][RS][LD]
-    unsigned char* const Xs = smem + 2 * RS * LD;           // [2][RS][LD]
+    unsigned char* const Ys = smem;                         // [2][PL][RS][LD]
+    unsigned char* const Xs = smem + 2 * PL * RS * LD;      // [2][PL][RS][LD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -358,13 +393,21 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
         }
     };
     auto store_stage = [&](int buf, int st, const u32x4* ry, const u32x4* rx) {
-        unsigned char* y = Ys + buf * RS * LD;
-        unsigned char* x = Xs + buf * RS * LD;
+        unsigned char* y = Ys + buf * PL * RS * LD;
+        unsigned char* x = Xs + buf * PL * RS * LD;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int id = tid + 256 * q, row = id / CPR, c = id % CPR;
+            if constexpr (X3) {
+                u32x2 hi, lo;
+                split_bf16x3(ry[q], hi, lo);
+                *(u32x2*)(y + row * LD + c * 8) = hi; *(u32x2*)(y + RS * LD + row * LD + c * 8) = lo;
+                split_bf16x3(rx[q], hi, lo);
+                *(u32x2*)(x + row * LD + c * 8) = hi; *(u32x2*)(x + RS * LD + row * LD + c * 8) = lo;
+            } else {
             *(u32x4*)(y + row * LD + c * 16) = ry[q];
             *(u32x4*)(x + row * LD + c * 16) = rx[q];
+            }
         }
     };
 
@@ -391,8 +434,23 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                 // a conditional load makes the number of younger loads path-dependent, and hipcc then falls back
                 // from counted s_waitcnt vmcnt(N) to vmcnt(0) at the next use -- which drains the whole ring
                 load_stage(min(st + NS, nst - 1), rY[s], rX[s]);
-                const unsigned char* y = Ys + buf * RS * LD;
-                const unsigned char* x = Xs + buf * RS * LD;
+                const unsigned char* y = Ys + buf * PL * RS * LD;
+                const unsigned char* x = Xs + buf * PL * RS * LD;
+                if constexpr (X3) {
+                    u32x4 ah[4], al[4];
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        ah[mt] = frag_tr16(y, LD, 0, wm * 64 + mt * 16, lane);
+                        al[mt] = frag_tr16(y + RS * LD, LD, 0, wm * 64 + mt * 16, lane);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const u32x4 bh = frag_tr16(x, LD, 0, wn * 64 + nt * 16, lane);
+                        const u32x4 bl = frag_tr16(x + RS * LD, LD, 0, wn * 64 + nt * 16, lane);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = mma16_x3(ah[mt], al[mt], bh, bl, acc[mt][nt]);
+                    }
+                } else
 #ifdef GE2E_WGRAD_ABL
                 if constexpr ((GE2E_WGRAD_ABL & 1) == 0)
 #endif
@@ -412,7 +470,10 @@ __global__ void __launch_bounds__(256) wgrad_kernel(const WgradArgs p) {
                 if (do_bias) {
                     const int col = tid & 127, half = tid >> 7;
 #pragma unroll 4
-                    for (int r = half * (RS / 2); r < (half + 1) * (RS / 2); ++r) bsum += to_f32(*(const T*)(y + r * LD + col * sizeof(T)));
+                    for (int r = half * (RS / 2); r < (half + 1) * (RS / 2); ++r) {
+                        if constexpr (X3) bsum += to_f32(*(const bf16_t*)(y + r * LD + col * 2)) + to_f32(*(const bf16_t*)(y + RS * LD + r * LD + col * 2));
+                        else bsum += to_f32(*(const T*)(y + r * LD + col * sizeof(T)));
+                    }
                 }
             }
         }
