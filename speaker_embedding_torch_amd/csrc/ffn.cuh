@@ -41,6 +41,8 @@
 
 namespace ge2e {
 
+typedef __attribute__((ext_vector_type(16))) float ffn_f32x16;      // (FFN_MF32_PROBE only)
+
 struct FfnArgs {
     const void* A; int lda;        // h1 [M, 256] of T: GEMM operand AND residual
     const void* W1;                // [F][256] of T   (linear1.weight, k-contiguous)
@@ -526,8 +528,14 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                     constexpr int j = decltype(J)::value;
                     rd(std::integral_constant<int, j + FRD>{});
                     ffn_lds_wait<FRD>(fr[j % FRB]);
+#ifdef FFN_MF32_PROBE
+                    // TIMING PROBE ONLY (tools/ffn_bench.hip -DFFN_MF32_PROBE; results wrong): ONE v_mfma_f32_32x32x16 of the same FLOPs for the
+                    // two 16x16x32 of this fragment, same operand registers, the stage's hidden accumulators as one 32 x 32 tile
+                    *(ffn_f32x16*)&h[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fr[j % FRB]), __builtin_bit_cast(bf16x8_t, af[j & 1][j >> 1]), *(ffn_f32x16*)&h[0][0], 0, 0, 0);
+#else
                     h[0][j & 1] = mm(fr[j % FRB], af[0][j >> 1], h[0][j & 1]);
                     h[1][j & 1] = mm(fr[j % FRB], af[1][j >> 1], h[1][j & 1]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 hidden_epilogue(h, hp, c);
@@ -535,8 +543,12 @@ __global__ void __launch_bounds__(64 * WV, WV == 8 ? 1 : 2) ffn_chain_kernel(con
                     constexpr int j = decltype(J)::value;
                     rd(std::integral_constant<int, j + FRD>{});
                     ffn_lds_wait<(j + FRD < 32 ? FRD : 31 - j)>(fr[j % FRB]);
+#ifdef FFN_MF32_PROBE
+                    ((ffn_f32x16*)&oacc[0][0])[(j - 16) >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fr[j % FRB]), __builtin_bit_cast(bf16x8_t, hp[j & 1]), ((ffn_f32x16*)&oacc[0][0])[(j - 16) >> 1], 0, 0, 0);
+#else
                     oacc[0][j - 16] = mm(fr[j % FRB], hp[0], oacc[0][j - 16]);
                     oacc[1][j - 16] = mm(fr[j % FRB], hp[1], oacc[1][j - 16]);
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                 });
             }

@@ -145,6 +145,20 @@ __global__ void __launch_bounds__(512) wgrad_ks_kernel(const WgradKsArgs p) {
         for (int nt = 0; nt < 8; ++nt) wk_tr_read(f[4 + nt], tb[nt] + sox);
     };
     auto mfmas = [&](const u32x4* f) {
+#ifdef WK_MF32_PROBE
+        // TIMING PROBE ONLY (tools/wgrad_ks_bench.hip -DWK_MF32_PROBE; the results are wrong): the stage's 32 v_mfma_f32_16x16x32 replaced by the 16
+        // v_mfma_f32_32x32x16 of the same FLOPs on the same 12 fragments and 128 accumulator registers -- what the larger shape could buy at
+        // best.  Measured: profiles/r04_ab_log.txt.
+        typedef __attribute__((ext_vector_type(16))) float f32x16;
+        f32x16* const a32 = (f32x16*)&acc[0][0];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                a32[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, f[2 * (q & 1) + ks]), __builtin_bit_cast(bf16x8_t, f[4 + 2 * (q >> 1) + ks]), a32[q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+#endif
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt)
 #pragma unroll

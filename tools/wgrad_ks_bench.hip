@@ -17,7 +17,6 @@ __global__ void fill_bf16(bf16_t* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
     using T = bf16_t; const int R = 153600;
     const int cap = argc > 1 ? atoi(argv[1]) : 160;
-    const int flat = argc > 2 ? atoi(argv[2]) : 0;
     T *Y, *X; float *dW, *dW2, *db, *db2, *part;
     CHECK(hipMalloc(&Y, (size_t)R * 1024 * 2)); CHECK(hipMalloc(&X, (size_t)R * 1024 * 2));
     CHECK(hipMalloc(&dW, 1024 * 1024 * 4)); CHECK(hipMalloc(&dW2, 1024 * 1024 * 4)); CHECK(hipMalloc(&db, 4096)); CHECK(hipMalloc(&db2, 4096));
@@ -49,7 +48,7 @@ int main(int argc, char** argv) {
         const int sps = (stages + splits - 1) / splits;
         splits = (stages + sps - 1) / sps;
         WgradKsArgs k{}; k.Y = Y; k.ldy = sh.ldy; k.X = X; k.ldx = sh.K; k.part = part; k.db = db2; k.R32 = R; k.rows_per_split = sps * 32;
-        k.tiles_n = tn; k.tiles_k = tk; k.splits = splits; k.flat_order = flat;
+        k.tiles_n = tn; k.tiles_k = tk; k.splits = splits;
         const int grid = 8 * ntile * ((splits + 7) / 8), sgroups = std::max(1, std::min(splits, 256 / (ntile * 32)));
         auto run = [&]() {
             hipLaunchKernelGGL(wgrad_ks_kernel<T>, dim3(grid), dim3(512), wgrad_ks_smem(), 0, k);
