@@ -129,7 +129,7 @@ __device__ __forceinline__ void rows8(f32x4* xv, const T* xb, int Tn, int lane, 
 // dynamic LDS: (6 * 256 + 16 * 256 + 4 * T) floats
 inline size_t attn_last_fwd_smem(int T) { return (size_t)(6 * 256 + 16 * 256 + 4 * T) * 4; }
 template <typename T>
-__global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p) {
+__global__ void __launch_bounds__(256, 4) attn_last_fwd_kernel(const AttnLastArgs p) {
     using namespace attn_last;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* const qs = sm;                      // [256] q0, later the output row
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p
     float* const sps = qt + 1024;              // [4] sum of the dropped probabilities (+ padding to 256)
     float* const red = sps + 256;              // [4 waves][4 heads][256]
     float* const sc = red + 4096;              // [4][T] scores, then dropped probabilities
-    const int n = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
+    const int n = blockIdx.x, c = threadIdx.x, lane = c & 63, w = __builtin_amdgcn_readfirstlane(c >> 6);     // (wave-uniform: row addresses become scalar base + lane offset)
     const int Tn = p.T;
     const T* const xb = (const T*)p.x + (size_t)n * Tn * D;
     qs[c] = to_f32(((const T*)p.q0)[(size_t)n * D + c]);
@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256) attn_last_fwd_kernel(const AttnLastArgs p
 
 inline size_t attn_last_bwd_smem(int T) { return (size_t)(256 + 1024 + 1024 + 4096 + 256 + 256 + 256 + 8 * T) * 4; }
 template <typename T>
-__global__ void __launch_bounds__(256) attn_last_bwd_kernel(const AttnLastArgs p) {
+__global__ void __launch_bounds__(256, 4) attn_last_bwd_kernel(const AttnLastArgs p) {
     using namespace attn_last;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* const dos = sm;                     // [256] do
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) attn_last_bwd_kernel(const AttnLastArgs p
     float* const dob = dq0s + 256;             // [4] do_h . bv_h (+ padding)
     float* const dpt = dob + 256;              // [4][T] dpd_t, then pd_t
     float* const dst = dpt + 4 * p.T;          // [4][T] ds_t
-    const int n = blockIdx.x, c = threadIdx.x, lane = c & 63, w = c >> 6;
+    const int n = blockIdx.x, c = threadIdx.x, lane = c & 63, w = __builtin_amdgcn_readfirstlane(c >> 6);     // (wave-uniform: row addresses become scalar base + lane offset)
     const int Tn = p.T;
     const T* const xb = (const T*)p.x + (size_t)n * Tn * D;
     dos[c] = to_f32(((const T*)p.do0)[(size_t)n * D + c]);

@@ -2,6 +2,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I speaker_embedding_torch_amd/csrc tools/attn_last_bench.hip -o tools/attn_last_bench
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <type_traits>
 #include "attn_last.cuh"
 using namespace ge2e;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
@@ -22,7 +26,40 @@ template <typename K> float time_kernel(K launch, int iters = 20) {
     float ms; CHECK(hipEventElapsedTime(&ms, a, b)); CHECK(hipGetLastError());
     return ms / iters * 1e3f;
 }
-int main() {
+// forward determinism: the same launch five times, outputs compared bit for bit (tools/attn_last_bench det [T] [N])
+template <typename T_> int determinism(int N, int T) {
+    T_ *x, *q0, *W, *o0; float* bv; unsigned short* ref;
+    CHECK(hipMalloc(&x, (size_t)N * T * 256 * 2)); CHECK(hipMalloc(&q0, N * 512)); CHECK(hipMalloc(&W, 768 * 512)); CHECK(hipMalloc(&o0, N * 512)); CHECK(hipMalloc(&bv, 1024));
+    fill_bf16<<<2048, 256>>>((bf16_t*)x, (size_t)N * T * 256, 1, 1.0f); fill_bf16<<<64, 256>>>((bf16_t*)q0, N * 256, 2, 1.0f); fill_bf16<<<64, 256>>>((bf16_t*)W, 768 * 256, 3, 0.06f);
+    if (sizeof(T_) == 2 && std::is_same<T_, f16_t>::value) {      // the same bit patterns read as halves would be huge: refill with half values
+        std::vector<unsigned short> hx((size_t)N * T * 256), hq((size_t)N * 256), hw(768 * 256);
+        auto gen = [](std::vector<unsigned short>& v, unsigned seed, float amp) { for (size_t i = 0; i < v.size(); ++i) { _Float16 f = (_Float16)((((mix32((unsigned)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f)) - 1.0f) * amp); memcpy(&v[i], &f, 2); } };
+        gen(hx, 1, 1.0f); gen(hq, 2, 1.0f); gen(hw, 3, 0.06f);
+        CHECK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(q0, hq.data(), hq.size() * 2, hipMemcpyHostToDevice)); CHECK(hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
+    }
+    fill_f32<<<1, 256>>>(bv, 256, 6, 0.0f);
+    CHECK(hipDeviceSynchronize());
+    AttnLastArgs a{};
+    a.x = x; a.q0 = q0; a.Wq = W; a.Wk = W + 256 * 256; a.Wv = W + 512 * 256; a.bv = bv; a.o0 = o0; a.T = T; a.H = 4; a.scale = 0.125f;
+    auto f0 = attn_last_fwd_kernel<T_>;
+    std::vector<unsigned short> first((size_t)N * 256), cur((size_t)N * 256);
+    int bad = 0;
+    for (int rep = 0; rep < 5; ++rep) {
+        CHECK(hipMemset(o0, 0xFF, N * 512));
+        hipLaunchKernelGGL(f0, dim3(N), dim3(256), attn_last_fwd_smem(T), 0, a);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipMemcpy(cur.data(), o0, N * 512, hipMemcpyDeviceToHost));
+        if (rep == 0) first = cur;
+        else { size_t d = 0, firstrow = (size_t)-1; for (size_t e = 0; e < cur.size(); ++e) if (cur[e] != first[e]) { ++d; if (firstrow == (size_t)-1) firstrow = e / 256; }
+               printf("%s T %d N %d launch %d: %zu elements differ from launch 0 (first row %zd)\n", sizeof(T_) == 4 ? "fp32" : (std::is_same<T_, f16_t>::value ? "fp16" : "bf16"), T, N, rep, d, (ssize_t)firstrow); bad += d != 0; }
+    }
+    return bad;
+}
+int main(int argc, char** argv) {
+    if (argc > 1 && std::string(argv[1]) == "det") {
+        const int T = argc > 2 ? atoi(argv[2]) : 64, N = argc > 3 ? atoi(argv[3]) : 1280;
+        return determinism<bf16_t>(N, T) + determinism<f16_t>(N, T);
+    }
     const int N = 960, T = 160;
     bf16_t *x, *q0, *W, *o0, *do0, *dpre, *dX, *dq0; float *bv, *qk, *prob, *ctx, *sp, *dqk;
     CHECK(hipMalloc(&x, (size_t)N * T * 256 * 2)); CHECK(hipMalloc(&dX, (size_t)N * T * 256 * 2)); CHECK(hipMalloc(&q0, N * 512)); CHECK(hipMalloc(&W, 768 * 512));
