@@ -6,6 +6,7 @@
 // directly as operands (no LDS round trip; guide section 3 "accumulator tile as the next operand").
 #pragma once
 #include "common.cuh"
+#include <type_traits>
 
 namespace ge2e {
 
@@ -30,6 +31,7 @@ template <typename T> struct ExpK;
 template <> struct ExpK<float> { static constexpr float K = 1.0f; static __device__ __forceinline__ float ex(float x) { return expf(x); } };
 template <> struct ExpK<bf16_t> { static constexpr float K = 1.4426950408889634f; static __device__ __forceinline__ float ex(float x) { return __builtin_amdgcn_exp2f(x); } };
 template <> struct ExpK<f16_t> : ExpK<bf16_t> {};
+template <> struct ExpK<x3_t> : ExpK<bf16_t> {};        // fp32x3: v_exp_f32 (~1 ulp of fp32), as the 16-bit modes
 
 namespace attn {
 // LDS image of a [rows][64] head tile, read BOTH by rows (ds_read_b128 operand fragments) and transposed (ds_read_b64_tr_b16):
@@ -96,6 +98,111 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
         acc = mma16<T>(lds16(tile + toff<T>(16 * t + i, k * 4 + g)), f[k], acc);
     return acc;
 }
+
+// ---- the same tile operations with the arithmetic mode as a parameter of the FRAGMENT type (resident kernels) --------------------------------
+// fp32x3 (T = x3_t; common.cuh): q | k | v and dO are fp32 in memory; in LDS a head tile is TWO planes of the 16-bit geometry (the bf16 hi
+// halves, then -- `po` bytes further -- the lo halves), split once on the way in; an operand fragment is a (hi, lo) pair and a product three
+// MFMAs.  The probabilities / dS tiles are split the same way when they become operands.
+template <typename T> struct XGeo : Geo<T> { static constexpr int PLANES = 1; };
+template <> struct XGeo<x3_t> {
+    static constexpr int ROWB = 128, LD = 128, CPR = 8, NKG = 2, PLANES = 2;
+    static constexpr bool SWZ = true;
+};
+template <typename T> constexpr int xtile_bytes(int rows) { return rows * XGeo<T>::LD * XGeo<T>::PLANES; }
+template <typename T> struct Frag { u32x4 h; };
+template <> struct Frag<x3_t> { u32x4 h, l; };
+template <typename T> __device__ __forceinline__ int xtoff(int row, int chunk) {
+    if constexpr (std::is_same<T, x3_t>::value) return toff<bf16_t>(row, chunk);
+    else return toff<T>(row, chunk);
+}
+template <typename T> __device__ __forceinline__ f32x4 xmma(const Frag<T>& a, const Frag<T>& b, f32x4 c) {
+    if constexpr (std::is_same<T, x3_t>::value) return mma16_x3(a.h, a.l, b.h, b.l, c);
+    else return mma16<T>(a.h, b.h, c);
+}
+// accumulator tiles -> operand fragment ("acc mapping" of pack_acc); fp32x3: hi = bf16(v), lo = bf16(v - hi)
+template <typename T> __device__ __forceinline__ Frag<T> xpack(f32x4 t0, f32x4 t1) {
+    if constexpr (std::is_same<T, x3_t>::value) {
+        Frag<x3_t> f;
+        f.h = pack_acc<bf16_t>(t0, t1);
+        f32x4 r0, r1;
+        r0[0] = t0[0] - __uint_as_float(f.h.x << 16); r0[1] = t0[1] - __uint_as_float(f.h.x & 0xFFFF0000u);
+        r0[2] = t0[2] - __uint_as_float(f.h.y << 16); r0[3] = t0[3] - __uint_as_float(f.h.y & 0xFFFF0000u);
+        r1[0] = t1[0] - __uint_as_float(f.h.z << 16); r1[1] = t1[1] - __uint_as_float(f.h.z & 0xFFFF0000u);
+        r1[2] = t1[2] - __uint_as_float(f.h.w << 16); r1[3] = t1[3] - __uint_as_float(f.h.w & 0xFFFF0000u);
+        f.l = pack_acc<bf16_t>(r0, r1);
+        return f;
+    } else return Frag<T>{pack_acc<T>(t0, t1)};
+}
+template <typename T> __device__ __forceinline__ Frag<T> xtile_tr(const unsigned char* tile, int po, int r0, int c0, int lane) {
+    if constexpr (std::is_same<T, x3_t>::value) return Frag<x3_t>{tile_tr<bf16_t>(tile, r0, c0, lane), tile_tr<bf16_t>(tile + po, r0, c0, lane)};
+    else return Frag<T>{tile_tr<T>(tile, r0, c0, lane)};
+}
+template <typename T>
+__device__ __forceinline__ void xload_tile(unsigned char* dst, int po, const unsigned char* src, size_t src_ld_bytes, int T_, int TP) {
+    if constexpr (std::is_same<T, x3_t>::value) {
+        for (int id = threadIdx.x; id < TP * 16; id += blockDim.x) {      // 16-byte chunks of four floats: chunk c of a row = k values 4c .. 4c + 3
+            const int row = id >> 4, c = id & 15;
+            u32x4 v = u32x4{0, 0, 0, 0};
+            if (row < T_) v = *(const u32x4*)(src + (size_t)row * src_ld_bytes + c * 16);
+            u32x2 hi, lo;
+            split_bf16x3(v, hi, lo);
+            const int o = toff<bf16_t>(row, c >> 1) + 8 * (c & 1);
+            *(u32x2*)(dst + o) = hi;
+            *(u32x2*)(dst + po + o) = lo;
+        }
+    } else load_tile<T>(dst, src, src_ld_bytes, T_, TP);
+}
+template <typename T>
+__device__ __forceinline__ void xrow_frags(Frag<T>* f, const unsigned char* src, size_t src_ld_bytes, int row, bool valid, int g) {
+    if constexpr (std::is_same<T, x3_t>::value) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                                     // k values 32 k + 8 g .. + 7: two chunks of four floats
+            const unsigned char* q = src + (size_t)row * src_ld_bytes + (32 * k + 8 * g) * 4;
+            const u32x4 a = valid ? *(const u32x4*)q : u32x4{0, 0, 0, 0}, b = valid ? *(const u32x4*)(q + 16) : u32x4{0, 0, 0, 0};
+            u32x2 ha, la, hb, lb;
+            split_bf16x3(a, ha, la); split_bf16x3(b, hb, lb);
+            f[k].h = u32x4{ha.x, ha.y, hb.x, hb.y};
+            f[k].l = u32x4{la.x, la.y, lb.x, lb.y};
+        }
+    } else {
+        u32x4 t[XGeo<T>::NKG];
+        load_row_frags<T>(t, src, src_ld_bytes, row, valid, g);
+#pragma unroll
+        for (int k = 0; k < XGeo<T>::NKG; ++k) f[k].h = t[k];
+    }
+}
+// this lane's row fragments from an LDS tile
+template <typename T> __device__ __forceinline__ Frag<T> xtile_frag(const unsigned char* tile, int po, int row, int chunk) {
+    if constexpr (std::is_same<T, x3_t>::value) return Frag<x3_t>{lds16(tile + toff<bf16_t>(row, chunk)), lds16(tile + po + toff<bf16_t>(row, chunk))};
+    else return Frag<T>{lds16(tile + toff<T>(row, chunk))};
+}
+template <typename T>
+__device__ __forceinline__ f32x4 xtile_dot(const unsigned char* tile, int po, int t, const Frag<T>* f, int i, int g) {
+    f32x4 acc = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < XGeo<T>::NKG; ++k) acc = xmma<T>(xtile_frag<T>(tile, po, 16 * t + i, k * 4 + g), f[k], acc);
+    return acc;
+}
+// this lane's share of a . b over the head dims its fragments hold (delta = dO . O)
+template <typename T> __device__ __forceinline__ float xrow_dot(const Frag<T>* a, const Frag<T>* b) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < XGeo<T>::NKG; ++k) {
+        if constexpr (std::is_same<T, x3_t>::value) {
+            const bf16_t* ah = (const bf16_t*)&a[k].h; const bf16_t* al = (const bf16_t*)&a[k].l;
+            const bf16_t* bh = (const bf16_t*)&b[k].h; const bf16_t* bl = (const bf16_t*)&b[k].l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += (to_f32(ah[e]) + to_f32(al[e])) * (to_f32(bh[e]) + to_f32(bl[e]));
+        } else {
+            const T* x = (const T*)&a[k].h; const T* y = (const T*)&b[k].h;
+#pragma unroll
+            for (int e = 0; e < Prec<T>::FRAG; ++e) s += to_f32(x[e]) * to_f32(y[e]);
+        }
+    }
+    return s;
+}
+// keep bytes handed from phase A to phase B through LDS (16-bit geometry; fp32x3 up to 256 frames: at 288 the four planes fill the LDS)
+template <typename T, int KT> constexpr bool use_mask() { return sizeof(T) == 2 || (std::is_same<T, x3_t>::value && KT <= 8); }
 }  // namespace attn
 
 // DROP is a COMPILE-TIME switch (the launcher tests drop.thr): as a run-time test of drop.thr inside the tile loops it split every
@@ -104,30 +211,31 @@ __device__ __forceinline__ f32x4 tile_dot(const unsigned char* tile, int t, cons
 // ABL (development only, tools/attn_bwd_bench.hip): 1 no compute (tile loads + barrier only), 4 no exp, 8 no P.V
 template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 1, int ABL = 0>
 __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
-    using G = attn::Geo<T>;
+    using G = attn::XGeo<T>;
     constexpr int TP = 32 * KT, NT16 = 2 * KT, KG = Prec<T>::KG, NG = TP / KG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Ks = smem;
-    unsigned char* const Vs = smem + TP * G::LD;
+    constexpr int PO = TP * G::LD;                            // fp32x3: offset of a tile's lo plane
+    unsigned char* const Vs = smem + attn::xtile_bytes<T>(TP);
     const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int i = lane & 15, g = lane >> 4;
     const size_t ldq = (size_t)3 * p.D * sizeof(T);
     const unsigned char* base = (const unsigned char*)p.qkv + (size_t)n * p.T * ldq + (size_t)h * 64 * sizeof(T);
-    attn::load_tile<T>(Ks, base + (size_t)p.D * sizeof(T), ldq, p.T, TP);
-    attn::load_tile<T>(Vs, base + (size_t)2 * p.D * sizeof(T), ldq, p.T, TP);
+    attn::xload_tile<T>(Ks, PO, base + (size_t)p.D * sizeof(T), ldq, p.T, TP);
+    attn::xload_tile<T>(Vs, PO, base + (size_t)2 * p.D * sizeof(T), ldq, p.T, TP);
     __syncthreads();
 
     for (int qt = wave; qt * 16 < p.T && !(ABL & 1); qt += nw) {       // wave-uniform loop: EXEC stays full
         const int qrow = qt * 16 + i;
         const bool vq = !PAD || qrow < p.T;                // PAD == false: T is a multiple of 32, no masking anywhere
-        u32x4 qf[G::NKG];
-        attn::load_row_frags<T>(qf, base, ldq, qrow, vq, g);
+        attn::Frag<T> qf[G::NKG];
+        attn::xrow_frags<T>(qf, base, ldq, qrow, vq, g);
         f32x4 s[NT16];
         float mx = -INFINITY;                              // maximum of the RAW scores (scale > 0)
 #pragma unroll
         for (int t = 0; t < NT16; ++t) { const int sb_i = t;
-            s[t] = attn::tile_dot<T>(Ks, t, qf, i, g);   // S^T[key 16t+4g+r][query qrow]
+            s[t] = attn::xtile_dot<T>(Ks, PO, t, qf, i, g);   // S^T[key 16t+4g+r][query qrow]
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);   // keep live ranges per tile (VGPR 173 -> 91)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -158,10 +266,10 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int gi = 0; gi < ((ABL & 8) ? 1 : NG); ++gi) { const int sb_i = gi;
-            const u32x4 pb = (KG == 32) ? pack_acc<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : pack_acc<T>(s[gi % NT16], s[gi % NT16]);
+            const attn::Frag<T> pb = (KG == 32) ? attn::xpack<T>(s[(2 * gi) % NT16], s[(2 * gi + 1) % NT16]) : attn::xpack<T>(s[gi % NT16], s[gi % NT16]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // O^T[d = 16dt+4g+r][query] += V^T[d][keys] * P^T[keys][query]
-                oacc[dt] = mma16<T>(attn::tile_tr<T>(Vs, gi * KG, dt * 16, lane), pb, oacc[dt]);
+                oacc[dt] = attn::xmma<T>(attn::xtile_tr<T>(Vs, PO, gi * KG, dt * 16, lane), pb, oacc[dt]);
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
@@ -183,18 +291,19 @@ __global__ void __launch_bounds__(512) attn_fwd_kernel(const AttnArgs p) {
 // ABL (development only, tools/attn_bwd_bench.hip): 1 no phase B, 2 no phase A, 8 no exp
 template <typename T, int KT, bool PAD = true, bool DROP = true, int SBE = 5, int ABL = 0, int MINB = 1>
 __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
-    using G = attn::Geo<T>;
+    using G = attn::XGeo<T>;
     constexpr int TP = 32 * KT, KG = Prec<T>::KG, NG = TP / KG, TPG = KG / 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const bufA = smem;
-    unsigned char* const bufB = smem + TP * G::LD;
-    float* const st_l = (float*)(smem + 2 * TP * G::LD);     // lse (times ExpK) per query of this head
+    constexpr int PO = TP * G::LD;                            // fp32x3: offset of a tile's lo plane
+    unsigned char* const bufB = smem + attn::xtile_bytes<T>(TP);
+    float* const st_l = (float*)(smem + 2 * attn::xtile_bytes<T>(TP));     // lse (times ExpK) per query of this head
     float* const st_d = st_l + TP;                            // delta * scale per query
     // The 16-bit modes hash the dropout keep bits once (phase A) and hand them to phase B through LDS; fp32 mode (parity
     // path; its K/V tiles already fill the LDS at 288 frames) re-hashes in phase B instead.  One BYTE per (4 keys, query), key
     // quad major: phase A's lane (keys 16t + 4g .. + 3, query) stores its nibble as one byte, no atomics and no clearing; phase B's
     // lane (queries 16t + 4g .. + 3, key) finds its four bytes in ONE word.
-    constexpr bool USE_MASK = sizeof(T) == 2;
+    constexpr bool USE_MASK = attn::use_mask<T, KT>();
     unsigned char* const st_m = (unsigned char*)(st_d + TP);  // [TP / 4][TP]
     const int n = blockIdx.x / p.H, h = blockIdx.x % p.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -210,8 +319,8 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
     const uint32_t T4 = (uint32_t)((p.T + 3) & ~3);
 
     // ---------------------------------------------------------------- phase A
-    attn::load_tile<T>(bufA, kbase, ldq, p.T, TP);
-    attn::load_tile<T>(bufB, vbase, ldq, p.T, TP);
+    attn::xload_tile<T>(bufA, PO, kbase, ldq, p.T, TP);
+    attn::xload_tile<T>(bufB, PO, vbase, ldq, p.T, TP);
     for (int q = threadIdx.x; q < TP; q += blockDim.x) {
         st_l[q] = q < p.T ? p.lse[((size_t)n * p.T + q) * p.H + h] * ExpK<T>::K : 0.0f;
         st_d[q] = 0.0f;          // padded queries: phase B multiplies (dP - delta) by P = 0, so delta must be finite
@@ -222,20 +331,14 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
     for (int qt = wave; qt * 16 < p.T && !(ABL & 2); qt += nw) {
         const int qrow = qt * 16 + i;
         const bool vq = !PAD || qrow < p.T;
-        u32x4 qf[G::NKG], dof[G::NKG];
-        attn::load_row_frags<T>(qf, qbase, ldq, qrow, vq, g);
-        attn::load_row_frags<T>(dof, dobase, ldo, qrow, vq, g);
+        attn::Frag<T> qf[G::NKG], dof[G::NKG];
+        attn::xrow_frags<T>(qf, qbase, ldq, qrow, vq, g);
+        attn::xrow_frags<T>(dof, dobase, ldo, qrow, vq, g);
         float delta = 0.0f;
         {
-            u32x4 of[G::NKG];
-            attn::load_row_frags<T>(of, obase, ldo, qrow, vq, g);
-#pragma unroll
-            for (int k = 0; k < G::NKG; ++k) {
-                const T* a = (const T*)&dof[k];
-                const T* b = (const T*)&of[k];
-#pragma unroll
-                for (int e = 0; e < Prec<T>::FRAG; ++e) delta += to_f32(a[e]) * to_f32(b[e]);
-            }
+            attn::Frag<T> of[G::NKG];
+            attn::xrow_frags<T>(of, obase, ldo, qrow, vq, g);
+            delta = attn::xrow_dot<T>(dof, of);
         }
         const float dsc = cross4_sum(delta) * p.scale;
         if (g == 0 && vq) st_d[qrow] = dsc;
@@ -251,8 +354,8 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int u = 0; u < TPG; ++u) {
                 const int t = gi * TPG + u;
-                const f32x4 sa = attn::tile_dot<T>(bufA, t, qf, i, g);     // S^T[key 16t+4g+r][query]
-                f32x4 dp = attn::tile_dot<T>(bufB, t, dof, i, g);          // d(P dropped)^T[key][query]
+                const f32x4 sa = attn::xtile_dot<T>(bufA, PO, t, qf, i, g);     // S^T[key 16t+4g+r][query]
+                f32x4 dp = attn::xtile_dot<T>(bufB, PO, t, dof, i, g);          // d(P dropped)^T[key][query]
                 if constexpr (DROP) {      // keep bits are hashed once, here; phase B reads them back from LDS
                     const uint32_t m = drop_select4(p.drop, ibase + (uint32_t)(16 * t + 4 * g), dp);
                     if constexpr (USE_MASK) st_m[(4 * t + g) * TP + qrow] = (unsigned char)m;
@@ -264,10 +367,10 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                     ds[u][r] = pr * (dp[r] * sds - dsc);
                 }
             }
-            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
+            const attn::Frag<T> sb = attn::xpack<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt)   // dQ^T[d][query] += K^T[d][keys] * dS^T[keys][query]
-                qacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, qacc[dt]);
+                qacc[dt] = attn::xmma<T>(attn::xtile_tr<T>(bufA, PO, gi * KG, dt * 16, lane), sb, qacc[dt]);
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }
         if (vq) {
@@ -278,15 +381,15 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
     }
     __syncthreads();
     // ---------------------------------------------------------------- phase B
-    attn::load_tile<T>(bufA, qbase, ldq, p.T, TP);
-    attn::load_tile<T>(bufB, dobase, ldo, p.T, TP);
+    attn::xload_tile<T>(bufA, PO, qbase, ldq, p.T, TP);
+    attn::xload_tile<T>(bufB, PO, dobase, ldo, p.T, TP);
     __syncthreads();
     for (int kt = wave; kt * 16 < p.T && !(ABL & 1); kt += nw) {
         const int krow = kt * 16 + i;
         const bool vk = !PAD || krow < p.T;
-        u32x4 kf[G::NKG], vf[G::NKG];
-        attn::load_row_frags<T>(kf, kbase, ldq, krow, vk, g);
-        attn::load_row_frags<T>(vf, vbase, ldq, krow, vk, g);
+        attn::Frag<T> kf[G::NKG], vf[G::NKG];
+        attn::xrow_frags<T>(kf, kbase, ldq, krow, vk, g);
+        attn::xrow_frags<T>(vf, vbase, ldq, krow, vk, g);
         f32x4 kacc[4], vacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) { kacc[dt] = f32x4{0, 0, 0, 0}; vacc[dt] = f32x4{0, 0, 0, 0}; }
@@ -300,8 +403,8 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
 #pragma unroll
             for (int u = 0; u < TPG; ++u) {
                 const int t = gi * TPG + u;
-                const f32x4 sa = attn::tile_dot<T>(bufA, t, kf, i, g);    // S[query 16t+4g+r][key krow]
-                const f32x4 da = attn::tile_dot<T>(bufB, t, vf, i, g);    // d(P dropped)[query][key]
+                const f32x4 sa = attn::xtile_dot<T>(bufA, PO, t, kf, i, g);    // S[query 16t+4g+r][key krow]
+                const f32x4 da = attn::xtile_dot<T>(bufB, PO, t, vf, i, g);    // d(P dropped)[query][key]
                 const f32x4 l4 = *(const f32x4*)(st_l + 16 * t + 4 * g);
                 const f32x4 d4 = *(const f32x4*)(st_d + 16 * t + 4 * g);
                 [[maybe_unused]] f32x4 keep4 = f32x4{1.0f, 1.0f, 1.0f, 1.0f};
@@ -323,12 +426,12 @@ __global__ void __launch_bounds__(512, MINB) attn_bwd_kernel(const AttnArgs p) {
                     ds[u][r] = (PAD && pr == 0.0f) ? 0.0f : pr * (dv * sds - d4[r]);
                 }
             }
-            const u32x4 pb = pack_acc<T>(pd[0], pd[TPG - 1]);
-            const u32x4 sb = pack_acc<T>(ds[0], ds[TPG - 1]);
+            const attn::Frag<T> pb = attn::xpack<T>(pd[0], pd[TPG - 1]);
+            const attn::Frag<T> sb = attn::xpack<T>(ds[0], ds[TPG - 1]);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                vacc[dt] = mma16<T>(attn::tile_tr<T>(bufB, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
-                kacc[dt] = mma16<T>(attn::tile_tr<T>(bufA, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
+                vacc[dt] = attn::xmma<T>(attn::xtile_tr<T>(bufB, PO, gi * KG, dt * 16, lane), pb, vacc[dt]);  // dV^T += dO^T Pd
+                kacc[dt] = attn::xmma<T>(attn::xtile_tr<T>(bufA, PO, gi * KG, dt * 16, lane), sb, kacc[dt]);  // dK^T += Q^T dS
             }
             if ((sb_i % SBE) == SBE - 1) __builtin_amdgcn_sched_barrier(0);
         }

@@ -212,7 +212,7 @@ __global__ void __launch_bounds__(256, 4) attn_last_fwd_kernel(const AttnLastArg
 
 inline size_t attn_last_bwd_smem(int T) { return (size_t)(256 + 1024 + 1024 + 4096 + 256 + 256 + 256 + 8 * T) * 4; }
 template <typename T>
-__global__ void __launch_bounds__(256, 4) attn_last_bwd_kernel(const AttnLastArgs p) {
+__global__ void __launch_bounds__(256, 3) attn_last_bwd_kernel(const AttnLastArgs p) {
     using namespace attn_last;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* const dos = sm;                     // [256] do

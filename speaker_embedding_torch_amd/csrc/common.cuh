@@ -36,6 +36,11 @@ template <> struct Prec<f16_t> {
     static constexpr int FRAG = 8;
     static constexpr int KG = 32;
 };
+struct x3_t;
+template <> struct Prec<x3_t> {      // fp32x3: the operands reach the matrix pipe as bf16 halves, 32 k values per MFMA
+    static constexpr int FRAG = 8;
+    static constexpr int KG = 32;
+};
 
 // ---------------------------------------------------------------------------------------------
 // mma16: C[16x16] += A[16 x KG] * B[KG x 16].   Lane l = 16*g + i supplies A[row i][slots of g]
@@ -77,6 +82,8 @@ __device__ __forceinline__ void split_bf16x3(u32x4 v, u32x2& hi, u32x2& lo) {
     lo.x = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r0, r1}, __attribute__((ext_vector_type(2))) __bf16));
     lo.y = __builtin_bit_cast(unsigned, __builtin_convertvector((__attribute__((ext_vector_type(2))) float){r2, r3}, __attribute__((ext_vector_type(2))) __bf16));
 }
+// Tag type of the fp32x3 mode for kernels whose LDS tiles and fragments change shape with it (attention.cuh): storage is a float.
+struct x3_t { float v; };
 // C += A.B from the split halves (small terms first)
 __device__ __forceinline__ f32x4 mma16_x3(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
     c = mma16<bf16_t>(al, bh, c);
@@ -153,6 +160,7 @@ __device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, floa
     u32x2 v; v.x = pack_f16x2(a, b); v.y = pack_f16x2(c, d);
     *(u32x2*)p = v;
 }
+__device__ __forceinline__ void store4(x3_t* p, float a, float b, float c, float d) { *(f32x4*)p = f32x4{a, b, c, d}; }
 __device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
 __device__ __forceinline__ f32x4 load4(const f16_t* p) {
     typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;

@@ -630,7 +630,6 @@ int launch_wgrad_tiled(ge2e_handle h, hipStream_t st, WgradArgs a) {
 
 template <typename T, int KT, bool PAD, bool DROP>
 int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd) {
-    using G = attn::Geo<T>;
     constexpr int TP = 32 * KT;
     const int qtiles = (a.T + 15) / 16;
     int nw = (qtiles + 1) / 2;
@@ -640,13 +639,13 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
     ProfScope ps(h, st, bwd ? GE2E_K_ATTN_BWD : GE2E_K_ATTN_FWD, (bwd ? 14.0 : 4.0) * a.T * a.T * 64.0 * n * a.H,
                  (double)n * a.T * a.D * sizeof(T) * (bwd ? 8.0 : 4.0));
     if (!bwd) {
-        const size_t smem = 2 * (size_t)TP * G::LD;
+        const size_t smem = 2 * (size_t)attn::xtile_bytes<T>(TP);
         // scheduling-barrier spacing of the score loop: every 5th tile (measured at 160 frames with the packed conversions: 95 us; every tile 119 us)
         constexpr int SBE = KT >= 3 ? 5 : (KT >= 2 ? 2 : 1);
         auto kern = attn_fwd_kernel<T, KT, PAD, DROP, SBE>;
         GE2E_LAUNCH(h, kern, grid, block, smem, st, a);
     } else {
-        size_t smem = 2 * (size_t)TP * G::LD + 2 * (size_t)TP * 4 + (sizeof(T) == 2 && DROP ? (size_t)TP * (TP / 4) : 0);    // + keep bits: a byte per (4 keys, query)
+        size_t smem = 2 * (size_t)attn::xtile_bytes<T>(TP) + 2 * (size_t)TP * 4 + (attn::use_mask<T, KT>() && DROP ? (size_t)TP * (TP / 4) : 0);    // + keep bits: a byte per (4 keys, query)
         // Two blocks of >= 5 waves per CU are enough for this kernel (960 x 160 alone: 310 us at 2 blocks per CU, 318-329 at 3, 415 at 1), and the
         // third block only takes registers and LDS from whatever the weight-gradient stream has in flight: a launch that would fit three asks
         // for a little more LDS than a third of the CU's (step 3.785 -> 3.742 ms).
@@ -683,7 +682,8 @@ int launch_attn_long(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bo
 
 template <typename T>
 int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bwd, float* delta = nullptr) {
-    if (a.T > 32 * MAX_KT) return launch_attn_long<T>(h, st, a, n, bwd, delta);
+    // (fp32x3: the chunked long-sequence kernels stay exact fp32 -- a functional path, the same tensors)
+    if (a.T > 32 * MAX_KT) return launch_attn_long<std::conditional_t<std::is_same<T, x3_t>::value, float, T>>(h, st, a, n, bwd, delta);
     const bool pad = a.T % 32 != 0;      // multiples of 32 frames need no key / query masking
     const bool drop = a.drop.thr != 0;   // dropout is a compile-time property of the kernels (attention.cuh)
 #define launch_attn_kt(TT, KK, PP) (drop ? launch_attn_kt<TT, KK, PP, true>(h, st, a, n, bwd) : launch_attn_kt<TT, KK, PP, false>(h, st, a, n, bwd))
@@ -910,7 +910,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.lse = train ? (float*)(ws + L.lse[l]) : nullptr;
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_attn(l));
-            CK(launch_attn<T>(h, st, a, n, false));
+            CK((launch_attn<std::conditional_t<X3 && sizeof(T) == 4, x3_t, T>>(h, st, a, n, false)));
         }
         {   // out_proj + dropout1 + residual + norm1
             GemmArgs a{};
@@ -1174,7 +1174,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.scale = 1.0f / std::sqrt((float)(d / c.heads));
             a.drop = make_drop(true, c.tf_dropout, seed, step, site_attn(l));
             sc.arm();
-            CK(launch_attn<T>(h, st, a, n, true, L.adelta != (size_t)-1 ? (float*)(ws + L.adelta) : nullptr));
+            CK((launch_attn<std::conditional_t<X3 && sizeof(T) == 4, x3_t, T>>(h, st, a, n, true, L.adelta != (size_t)-1 ? (float*)(ws + L.adelta) : nullptr)));
             sc.fork();
             WgradArgs w{};
             w.Y = b_dQKV; w.ldy = 3 * d; w.X = hin; w.ldx = d; w.dW = G(lp(l, L_IN_W)); w.ldw = d; w.db = G(lp(l, L_IN_B));

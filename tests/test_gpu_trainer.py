@@ -473,3 +473,53 @@ def test_bucket_schedule_through_a_one_rank_rccl_group(tmp_path):
             continue
         cos = float(g @ rr / max(np.linalg.norm(g) * np.linalg.norm(rr), 1e-30))
         assert cos > 0.99 and rel_l2(g, rr) < 0.15, (name, cos, rel_l2(g, rr))
+
+
+@pytest.mark.parametrize("where,value", [("transformer.layers.0.linear1.weight", float("inf")), ("transformer.layers.0.linear1.bias", float("nan")),
+                                          ("transformer.layers.1.linear2.weight", float("-inf"))])
+def test_non_finite_hidden_activations_still_skip_the_scaled_step(where, value):
+    """the chained FFN applies ReLU and dropout as INTEGER operations on packed 16-bit pairs (common.cuh pk_relu16 / pk_keep16): a NaN
+    whose sign bit is set becomes +0 and a dropped Inf / NaN becomes 0, where torch.relu / dropout propagate the NaN.  The loss scaler's skip
+    decision (reference Train.py:153-162: GradScaler.step skips on inf / nan gradients) must survive that: a non-finite FFN weight or bias makes
+    whole hidden COLUMNS non-finite (+Inf and positive NaN pass the packed ReLU, kept elements pass the dropout), so the layer output, the loss
+    and every gradient are non-finite, found_inf is set, parameters and moments stay untouched and the scale backs off.
+    (What the packed forms can hide is a lone NEGATIVE-signed NaN in a hidden activation whose inputs are all finite -- which finite
+    weights and finite LayerNorm outputs cannot produce.)"""
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    from speaker_embedding_torch_amd.Optim import FusedClipAdamW, GradScaler
+    import test_gpu_parity as tp
+    m, _, _ = tp.build(GE2E, "fp16", 0.1)
+    m.train()
+    opt = FusedClipAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)
+    sc = GradScaler(init_scale=1024.0)
+    x = torch.from_numpy(O.formula_mel(9, 12, 80, 77, logmel=True)).cuda()
+    crit = GE2E_Loss().cuda()
+    for q in crit.parameters():
+        q.requires_grad_(False)
+
+    def one_step():
+        opt.zero_grad()
+        loss = crit(m(x), 3)
+        sc.backward(loss)
+        sc.step(opt)
+        sc.update()
+        return loss
+
+    loss = one_step()                                                       # a clean step first: moments exist, scale unchanged
+    assert torch.isfinite(loss) and float(sc.state(x.device)[2]) == 0.0 and sc.get_scale() == 1024.0
+    prm = dict(m.named_parameters())[where]
+    with torch.no_grad():
+        prm.view(-1)[7] = value
+    m._prepared_key = None
+    before = [q.detach().clone() for q in m.parameters()]
+    state_before = {k: {kk: vv.clone() if torch.is_tensor(vv) else vv for kk, vv in st.items()} for k, st in opt.state_dict()["state"].items()}
+    loss = one_step()
+    assert not torch.isfinite(loss), "a non-finite FFN parameter must reach the loss"
+    assert float(sc.state(x.device)[2]) == 1.0, "found_inf not set: the step was NOT skipped"
+    assert sc.get_scale() == 512.0 and sc.steps_taken() == 1
+    for q, b in zip(m.parameters(), before):
+        assert torch.equal(torch.nan_to_num(q.detach(), nan=123.0, posinf=456.0, neginf=-456.0), torch.nan_to_num(b, nan=123.0, posinf=456.0, neginf=-456.0))
+    for k, st in opt.state_dict()["state"].items():
+        for kk, vv in st.items():
+            if torch.is_tensor(vv):
+                assert torch.equal(vv, state_before[k][kk]), (k, kk)
