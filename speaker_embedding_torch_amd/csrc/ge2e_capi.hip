@@ -466,11 +466,13 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         // microsecond -- eval 3.9 vs 3.7, train 3.2 vs 2.7 -- but its 256-row passes quantise: 600 passes (the headline batch) on
         // 256 CUs take three rounds with a quarter of the chip idle, where 1200 half-size passes on 512 half-CU slots flow
         // (measured alone: eval 160 vs 195 us, train 224 vs 238 us; 768,000 rows, 3000 passes: 826 vs 804 us).  Take the 8-wave
-        // shape when its rounds are full enough to keep its per-CU advantage.  GE2E_FFN_WV = 4 / 8 forces one.
+        // shape when its rounds are full enough to keep its per-CU advantage.  Option ffn_wv = 4 / 8 forces one (eval).
         const int wv_env = opt(O_FFN_WV);
         const int np8 = (a.M + 255) / 256, rounds8 = (np8 + h->num_cus - 1) / h->num_cus;
         const double fill8 = (double)np8 / ((double)rounds8 * h->num_cus);
-        const int wv = wv_env == 4 || wv_env == 8 ? wv_env : (fill8 >= (a.Fo ? 0.84 : 0.95) ? 8 : 4);
+        // (train mode always takes the 4-wave shape: its 8-wave instantiation was the one kernel of the library with scratch -- 36 bytes per lane in
+        // the pass prologue -- for ~3 % on batches whose 256-row passes fill the chip, e.g. configs[4]: 804 vs 826 us at 768,000 rows)
+        const int wv = a.Fo ? 4 : (wv_env == 4 || wv_env == 8 ? wv_env : (fill8 >= 0.95 ? 8 : 4));
         const int rows_pass = wv == 4 ? 128 : 256, slots = wv == 4 ? 2 * h->num_cus : h->num_cus;
         const int npass = (a.M + rows_pass - 1) / rows_pass;
         // every block runs ceil(npass / slots) passes: a grid of ceil(npass / that) blocks finishes at the same time as a full
@@ -484,10 +486,7 @@ int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
         if (wv == 4) {
             if (a.Fo) { auto kern = ffn_chain_kernel<T, true, 0, false, 4>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_smem<4>(), st, a, npass); }
             else { auto kern = ffn_chain_kernel<T, false, 0, false, 4>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(256), ffn_smem<4>(), st, a, npass); }
-        } else {
-            if (a.Fo) { auto kern = ffn_chain_kernel<T, true>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem<8>(), st, a, npass); }
-            else { auto kern = ffn_chain_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem<8>(), st, a, npass); }
-        }
+        } else { auto kern = ffn_chain_kernel<T, false>; GE2E_LAUNCH(h, kern, dim3(grid), dim3(512), ffn_smem<8>(), st, a, npass); }
         return 0;
     }
 }
