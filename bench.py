@@ -50,16 +50,20 @@ def synth_mel(n, mel, t, seed, device):
 
 
 def load_pmc_traffic(kernel):
-    """HBM bytes per launch of the class from the committed rocprofv3 --pmc passes (profiles/*_pmc_traffic.json:
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE); None until measured."""
+    """HBM bytes per launch of the class from the COMMITTED rocprofv3 --pmc passes (profiles/*_pmc_traffic.json: FETCH_SIZE doubled
+    as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE) and the file they came from -- the counters cannot be collected
+    inside this run (two separate --pmc passes under the profiler), so the line says where the figure was measured; (None, None)
+    until measured."""
     import glob
-    best = None
+    best, src = None, None
     for path in sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json"))):
         try:
-            best = json.load(open(path)).get(kernel, best)
+            v = json.load(open(path)).get(kernel)
         except Exception:
-            pass
-    return best
+            v = None
+        if v is not None:
+            best, src = v, os.path.relpath(path, REPO)
+    return best, src
 
 
 def cpu_baseline(speakers, utts, frames, mel, steps=3):
@@ -327,7 +331,8 @@ def main():
                 "achieved": round(gbs if hbm_bound else tf, 2), "peak": HBM_PEAK_GBS if hbm_bound else PEAK[args.precision],
                 "unit": "GB/s" if hbm_bound else "TFLOP/s",
                 "frac": round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / PEAK[args.precision]), 4),
-                "traffic": load_pmc_traffic(args.roofline_kernel),
+                "traffic": load_pmc_traffic(args.roofline_kernel)[0],
+                "traffic_source": f"committed rocprofv3 --pmc passes of this kernel class ({load_pmc_traffic(args.roofline_kernel)[1]}; tools/final_meas.sh), not collected in this run",
                 "launches": launches, "avg_launch_us": round(ms * 1e3 / launches, 2),
                 "class_ms_per_step": round(ms / max(profiled_steps, 1), 3), "profiled_steps": profiled_steps,
                 "algorithmic_flop_per_byte": round(ai, 1), "ridge_flop_per_byte": round(ridge, 1),

@@ -305,6 +305,34 @@ def test_f16_train_step_vs_oracle(mods, n, t, P, p, tag):
         assert cos > 0.999 and rel_l2(g, r) < 5e-2, (name, cos, rel_l2(g, r))
 
 
+@pytest.mark.parametrize("prec,n,t,P,tag", [("bf16", 20, 160, 5, 1), ("bf16", 12, 77, 3, 3), ("fp16", 20, 160, 5, 1), ("fp16", 12, 77, 3, 3)])
+def test_16bit_gradient_error_pinned_without_dropout(mods, prec, n, t, P, tag):
+    """the end-to-end 16-bit bounds of the dropout-on tests were widened to cover the variance of one mask sample (alpha: bf16 0.15 ->
+    0.3 of |d prenet.bias|, fp16 0.03 -> 0.05); a precision regression in a packed epilogue could hide under that.  With dropout OFF nothing varies:
+    the bounds here are round 2's TIGHT ones (alpha 0.15 / 0.03) halved, and per tensor the observed error + 30 % (profiles/r04_grad_err.txt: bf16
+    worst 0.162 = the last layer's linear1 on 20 compact rows, 0.117 elsewhere; fp16 0.040) -- so the widened limits above cover mask-sample
+    variance only."""
+    GE2E, GE2E_Loss = mods
+    m, params, pe = build(GE2E, prec, 0.0)
+    m.train()
+    x_np = O.formula_mel(tag, n, 80, t, logmel=True)
+    emb_ref, c = O.encoder_forward(params, x_np, train=True, seed=1234, step=0, p_pe=0.0, p_tf=0.0, pe=pe)
+    _, lc = O.loss_forward(emb_ref, P)
+    grads_ref = O.encoder_backward(params, c, O.loss_backward(lc))
+    scale = 4096.0 if prec == "fp16" else 1.0
+    (GE2E_Loss().cuda()(m(torch.from_numpy(x_np).cuda()), P) * scale).backward()
+    nb = np.linalg.norm(grads_ref["prenet.bias"])
+    a_lim, r_lim, r_last, c_min = (0.075, 0.155, 0.21, 0.985) if prec == "bf16" else (0.015, 0.052, 0.052, 0.9985)
+    for name, prm in m.named_parameters():
+        g, r = (prm.grad.cpu().numpy().ravel() / scale).astype(np.float64), grads_ref[name].ravel().astype(np.float64)
+        if g.size == 1:
+            assert abs(g[0] - r[0]) < a_lim * nb, (name, abs(g[0] - r[0]) / nb)
+            continue
+        cos = float(g @ r / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+        lim = r_last if name.startswith("transformer.layers.2.linear1") else r_lim
+        assert rel_l2(g, r) < lim and cos > c_min, (name, rel_l2(g, r), cos)
+
+
 @pytest.mark.parametrize("prec,n,t,P", [("fp32", 4, 512, 2), ("fp32", 3, 300, 3), ("bf16", 4, 512, 2), ("fp16", 4, 1024, 2)])
 def test_long_sequences_up_to_max_position(mods, prec, n, t, P):
     """reference Modules.py:107-109 slices the positional table for any T <= Max_Position (1024).  Beyond 288 frames the
