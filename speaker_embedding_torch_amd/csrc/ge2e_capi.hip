@@ -18,6 +18,7 @@
 
 #include "attention.cuh"
 #include "attn_last.cuh"
+#include "attn_sub.cuh"
 #include "prenet_bwd.cuh"
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
@@ -45,7 +46,7 @@ struct ParamInfo { std::string name; int64_t numel, offset; };
 // The ctypes loader forwards GE2E_<NAME> environment variables here only when GE2E_DEV_SWITCHES=1 (tools/ab.sh, tools/switch_test.sh).
 enum Opt {
     O_NO_OVERLAP, O_NO_WS_GEMM, O_NO_KL_GEMM, O_NO_LNFUSE, O_NO_SK_GEMM, O_NO_FFN_CHAIN, O_FFN_WV, O_NO_FFN_CHAIN_BWD, O_NO_WGRAD_KS,
-    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE,
+    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE, O_ATTN_SUB,
     O_DEBUG_BWD_STOP, O_DEBUG_SIDE_DELAY_US, O_COUNT
 };
 struct OptDef { const char* name; int def; };
@@ -65,6 +66,7 @@ constexpr OptDef OPT_DEFS[O_COUNT] = {
     {"no_maskbits", 0},         // dF reads the stored hidden as its mask
     {"no_colsum_end", 0},       // norm2 column sums on the weight-gradient stream
     {"no_prenet_fuse", 0},      // prenet backward as recompute GEMM + weight-gradient launch
+    {"attn_sub", 0},            // 1: in_proj, attention, out_proj + LayerNorm of a full layer as ONE launch per utterance (attn_sub.cuh; measured slower, off)
     {"debug_bwd_stop", -1},     // >= 0: backward returns after k layers (parity tests read that layer's scratch through ge2e_debug_tap)
     {"debug_side_delay_us", 0}, // tests: hold the weight-gradient stream back after every fork
 };
@@ -701,6 +703,43 @@ int launch_attn(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool bw
 #undef launch_attn_kt
 }
 
+// The attention sub-layer of a full layer as one kernel per utterance (attn_sub.cuh): 16-bit modes, 4 heads of 64, 49 .. 160 frames.  OPT-IN
+// (option attn_sub = 1): correct and tested, but measured SLOWER than the three launches it replaces (profiles/r04_ab_log.txt section 3).
+template <typename T>
+bool attn_sub_shape(const ge2e_config& c, int t) {
+    return sizeof(T) == 2 && opt(O_ATTN_SUB) && c.emb == 256 && c.heads == 4 && t > 48 && t <= 160;
+}
+template <typename T, int NW>
+int launch_attn_sub_nw(ge2e_handle h, hipStream_t st, const AttnSubArgs& a, int n) {
+    if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "attn_sub: 16-bit modes only");
+    else {
+        const bool pad = a.T % 32 != 0, drop = a.drop_attn.thr != 0;
+        constexpr size_t smem = attn_sub::smem_bytes<NW>();
+        const double rows = (double)n * a.T;
+        // algorithmic bytes: x in, h1 out, (train) q|k|v and o out, both weight matrices; FLOPs: in_proj + attention + out_proj
+        ProfScope ps(h, st, GE2E_K_ATTN_FWD, rows * (2.0 * 256 * 768 + 4.0 * a.T * 256 + 2.0 * 256 * 256),
+                     2.0 * (rows * 256 * (a.qkv ? 6.0 : 2.0) + 4.0 * 256 * 256));
+#define GE2E_SUB(PP, DD) do { auto kern = attn_sub_fwd_kernel<T, NW, PP, DD>; GE2E_LAUNCH(h, kern, dim3(n), dim3(64 * NW), smem, st, a); } while (0)
+        if (pad) { if (drop) GE2E_SUB(true, true); else GE2E_SUB(true, false); }
+        else { if (drop) GE2E_SUB(false, true); else GE2E_SUB(false, false); }
+#undef GE2E_SUB
+        return 0;
+    }
+}
+template <typename T>
+int launch_attn_sub(ge2e_handle h, hipStream_t st, const AttnSubArgs& a, int n) {
+    switch ((a.T + 15) / 16) {
+        case 4: return launch_attn_sub_nw<T, 4>(h, st, a, n);
+        case 5: return launch_attn_sub_nw<T, 5>(h, st, a, n);
+        case 6: return launch_attn_sub_nw<T, 6>(h, st, a, n);
+        case 7: return launch_attn_sub_nw<T, 7>(h, st, a, n);
+        case 8: return launch_attn_sub_nw<T, 8>(h, st, a, n);
+        case 9: return launch_attn_sub_nw<T, 9>(h, st, a, n);
+        case 10: return launch_attn_sub_nw<T, 10>(h, st, a, n);
+        default: return fail(h, GE2E_EUNSUPPORTED, "attn_sub: frame count not instantiated");
+    }
+}
+
 // last layer: one query per utterance, no K / V projection (attn_last.cuh)
 inline AttnLastArgs attn_last_args(const ge2e_config& c, const Layout& L, unsigned char* ws, const float* const* P, int l, int t, const void* x,
                                    bool train, const Drop& drop) {
@@ -886,6 +925,17 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         const bool last = l == c.layers - 1;
         const int Rl = last ? n : R, rmul = last ? t : 1;
         const size_t esz = L.esz;
+        if (!last && attn_sub_shape<T>(c, t)) {
+            // in_proj -> attention -> out_proj + dropout + residual + norm1 in ONE launch per layer (attn_sub.cuh); q|k|v, o, lse, rstd1 leave for the backward in train mode
+            AttnSubArgs a{};
+            a.X = hin; a.Win = ws + L.w_in[l]; a.bin = P[lp(l, L_IN_B)]; a.Wo = ws + L.w_out[l]; a.bo = P[lp(l, L_OUT_B)];
+            a.gamma = P[lp(l, L_N1_W)]; a.beta = P[lp(l, L_N1_B)]; a.eps = c.ln_eps;
+            a.qkv = train ? ws + L.qkv[l] : nullptr; a.o = train ? ws + L.o[l] : nullptr;
+            a.lse = train ? (float*)(ws + L.lse[l]) : nullptr; a.h1 = ws + L.h1[l]; a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
+            a.T = t; a.scale = 1.0f / std::sqrt((float)(d / c.heads));
+            a.drop_attn = make_drop(train, c.tf_dropout, seed, step, site_attn(l)); a.drop_sa = make_drop(train, c.tf_dropout, seed, step, site_sa(l));
+            CK(launch_attn_sub<T>(h, st, a, n));
+        } else {
         if (!last) {   // in_proj
             GemmArgs a{};
             a.A = hin; a.lda = d; a.W = ws + L.w_in[l]; a.ldw = d; a.C = ws + L.qkv[l]; a.ldc = 3 * d;
@@ -919,6 +969,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             a.rstd = train ? (float*)(ws + L.rstd1[l]) : nullptr;
             a.drop = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.drow_mul = rmul;
             CK((gemm_ln<T, X3>(h, st, a)));
+        }
         }
         if (sizeof(T) == 2 && !last && c.ffn == FFN_F && d == 256 && ffn_chain_on()) {
             // linear1 + ReLU + dropout + linear2 + dropout2 + residual + norm2, the hidden on chip (written once in train mode)

@@ -238,3 +238,36 @@ def test_every_16bit_kernel_against_fp64_of_its_own_inputs(mods, prec, n, t):  #
     dHa = tap("dHin.1", (R, d))
     close(dHa, dP2 + dQKV @ W[pre + "self_attn.in_proj_weight"], prec, "dH = dPre1 + dQKV Win (gemm_nt EPI_ADD, K = 768)")
     print("\n".join(f"  {a} {c:8.4f} eps  {b}" for a, b, c in OBSERVED[-40:]))
+
+
+@pytest.mark.parametrize("prec,n,t", [("bf16", 12, 160), ("fp16", 9, 150), ("bf16", 7, 77)])
+def test_fused_attention_sublayer_matches_its_three_launches(prec, n, t):
+    """attn_sub.cuh (option attn_sub = 1; SURVEY section 7's second fusion: in_proj -> attention -> out_proj + dropout + residual + norm1 in ONE launch per
+    utterance) against the three launches it replaces, same inputs, same dropout stream, train mode: q|k|v, the attention output and lse are the SAME
+    arithmetic in the same order (bitwise); h1 and rstd1 differ only in the order of the LayerNorm sums (one rounding of the storage type)."""
+    from speaker_embedding_torch_amd import _lib
+    from speaker_embedding_torch_amd.Modules import GE2E
+    import test_gpu_parity as tp
+    x = torch.from_numpy(O.formula_mel(13, n, 80, t, logmel=True)).cuda()
+    taps = {}
+    for mode in (0, 1):
+        _lib.set_option("attn_sub", mode)
+        try:
+            m, _, _ = tp.build(GE2E, prec, 0.1)
+            m.train()
+            emb = m(x)
+            torch.cuda.synchronize()
+            taps[mode] = {k: m.workspace_view(k, n, t, True).float().clone() for k in ("qkv.0", "o.0", "h1.0", "qkv.1", "o.1", "h1.1", "h2.1")}
+            taps[mode]["lse.0"] = m.workspace_view("lse.0", n, t, True, dtype=torch.float32).clone()
+            taps[mode]["rstd1.0"] = m.workspace_view("rstd1.0", n, t, True, dtype=torch.float32).clone()
+            taps[mode]["emb"] = emb.detach().clone()
+        finally:
+            _lib.set_option("attn_sub", 0)
+    a, b = taps[0], taps[1]
+    for k in ("qkv.0", "o.0", "lse.0"):
+        assert torch.equal(a[k], b[k]), k
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    assert (a["rstd1.0"] - b["rstd1.0"]).abs().max() <= 1e-5 * a["rstd1.0"].abs().max()
+    assert (a["h1.0"] - b["h1.0"]).abs().max() <= 2 * ulp * a["h1.0"].abs().max()
+    assert ((a["h1.0"] != b["h1.0"]).float().mean()) < 0.02              # a handful of single-ulp flips
+    assert tp.rel_l2(b["h2.1"].cpu().numpy(), a["h2.1"].cpu().numpy()) < 5e-3 and tp.rel_l2(b["emb"].cpu().numpy(), a["emb"].cpu().numpy()) < 5e-3
