@@ -634,6 +634,9 @@ int launch_attn_kt(ge2e_handle h, hipStream_t st, const AttnArgs& a, int n, bool
     constexpr int TP = 32 * KT;
     const int qtiles = (a.T + 15) / 16;
     int nw = (qtiles + 1) / 2;
+    // fp32x3: the four LDS planes of a block (88 KB at 160 frames) leave room for ONE block per CU, so the block takes up to 8 waves, one 16-row
+    // tile each where that covers the sequence (the 16-bit modes run 2-3 blocks of qtiles / 2 waves per CU)
+    if constexpr (std::is_same<T, x3_t>::value) nw = qtiles;
     if (nw > 8) nw = 8;
     if (nw < 1) nw = 1;
     const dim3 grid(n * a.H), block(64 * nw);
