@@ -70,6 +70,7 @@ constexpr OptDef OPT_DEFS[O_COUNT] = {
     {"debug_bwd_stop", -1},     // >= 0: backward returns after k layers (parity tests read that layer's scratch through ge2e_debug_tap)
     {"debug_side_delay_us", 0}, // tests: hold the weight-gradient stream back after every fork
 };
+static_assert(sizeof(OPT_DEFS) / sizeof(OPT_DEFS[0]) == O_COUNT, "one definition per option, in enum order");
 std::atomic<int> g_opt[O_COUNT];
 struct OptInit { OptInit() { for (int i = 0; i < O_COUNT; ++i) g_opt[i].store(OPT_DEFS[i].def, std::memory_order_relaxed); } } g_opt_init;
 inline int opt(int o) { return g_opt[o].load(std::memory_order_relaxed); }
@@ -1257,6 +1258,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             sc.fork();
             forked_after_dh = true;
             {   // k | v rows of in_proj_weight (and the v bias; the k bias has no gradient: its score term is constant over the frames)
+                // (Parked ~180 us behind the chained FFN backward's persistent blocks here; on the main stream in front of the fork, or at the end of
+                // the main chain, it is not -- and the step is no faster: 3.512-3.521 / 3.518-3.525 vs 3.501-3.504 ms, profiles/r04_ab_log.txt section 4.)
                 auto kern = attn_last_wgrad_kernel<T>;
                 const int chunks = std::max(1, std::min(16, n / 32)), per = (n + chunks - 1) / chunks;
                 float* const dW = G(lp(l, L_IN_W));

@@ -2,7 +2,7 @@
 """Soak test (development tool): many training steps on changing shapes, looking for hangs, faults and non-finite values.
     timeout -k 10 600 python tools/soak.py [--steps 1500] [--shapes 150]
 Phase 1: the benchmark shape, `--steps` consecutive Train_Steps (dropout stream advances every step).
-Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16, fp32 and fp16 in turn, fresh NaN-poisoned workspace,
+Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16, fp32, fp16 and fp32x3 in turn (every 5th with the fused attention sub-layer on), fresh NaN-poisoned workspace,
 one forward + backward + optimizer step each; every gradient must be finite."""
 import argparse, os, sys, time
 import numpy as np
@@ -10,6 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+from speaker_embedding_torch_amd import _lib
 from speaker_embedding_torch_amd.Optim import FusedClipAdamW
 
 
@@ -30,7 +31,8 @@ def main():
             assert np.isfinite(loss.item())
     rng = np.random.default_rng(0)
     for k in range(args.shapes):
-        S = int(rng.integers(2, 9)); P = int(rng.integers(2, 7)); prec = ("bf16", "fp32", "fp16")[k % 3]
+        S = int(rng.integers(2, 9)); P = int(rng.integers(2, 7)); prec = ("bf16", "fp32", "fp16", "fp32x3")[k % 4]
+        _lib.set_option("attn_sub", 1 if k % 5 == 4 else 0)          # every 5th shape: the opt-in fused attention sub-layer kernel (16-bit modes, 49-160 frames)
         T = int(rng.integers(289, 640)) if k % 12 == 11 else int(rng.integers(17, 289))       # every 12th shape: the chunked long-sequence attention
         m = GE2E(hp, precision=prec, seed=k).to(dev); m._poison = True; m.train()
         o = FusedClipAdamW(m.parameters(), lr=1e-4, betas=(0.9, 0.999), eps=1e-6, max_norm=1.0)
@@ -40,6 +42,7 @@ def main():
         if not ok or k % 25 == 24:
             print(f"phase 2 shape {k + 1}: S={S} P={P} T={T} {prec} loss {loss.item():.4f} finite={ok}", flush=True)
         assert ok, (S, P, T, prec)
+    _lib.set_option("attn_sub", 0)
     print("soak ok")
 
 
