@@ -45,6 +45,11 @@ int main(int argc, char** argv) {
     a.A = A; a.lda = 256; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.Fo = F; a.Mb = Mb; a.ldf = 1024; a.C = C; a.ldc = 256;
     a.gamma = ga; a.beta = be; a.rstd = rstd; a.eps = 1e-5f; a.M = M; a.drow_mul = 1;
     FfnArgs ad = a; ad.drop1 = Drop{12345u, 6553u, 1.1111f}; ad.drop2 = Drop{54321u, 6553u, 1.1111f};
+    if (argc > 2) {                               // PMC mode (tools/pmc_tcc_ffn.sh): the two shipped 4-wave kernels only
+        run<false, 0, 4>("eval  4-wave, 512 blocks", a, 512);
+        run<true, 0, 4>("train 4-wave, 512 blocks", ad, 512);
+        return 0;
+    }
     for (int rep = 0; rep < 3; ++rep) {          // A/B of the two block shapes, interleaved (the clocks ramp over the first launches)
         run<false, 0>("eval  8-wave, 200 blocks", a, 200);
         run<false, 0, 4>("eval  4-wave, 512 blocks", a, 512);
