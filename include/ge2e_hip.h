@@ -208,7 +208,9 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
                    size_t* offset_bytes, size_t* size_bytes);
 
 /* Development / diagnostic options.  The library never reads the process environment; the defaults are the shipped configuration.
- * An option is process-wide and takes effect at the next call that depends on it ("no_overlap": at the next ge2e_create).  Names
+ * An option is process-wide and takes effect at the next call that depends on it ("no_overlap": at the next ge2e_create); a call reads
+ * its options once, at entry, and a backward takes what its forward left in the workspace (the FFN mask as bits or not) from that
+ * forward's own record, so an option may change between a forward and its backward.  Names
  * (ge2e_option_name(0 .. ) enumerates them, NULL past the end): kernel-selection ablations "no_overlap", "no_ws_gemm", "no_kl_gemm",
  * "no_lnfuse", "no_sk_gemm", "no_ffn_chain", "ffn_wv" (4 | 8), "no_ffn_chain_bwd", "no_wgrad_ks", "no_reduce_batch",
  * "wgrad_ks_blocks" (n), "no_event_bind", "no_maskbits", "no_colsum_end", "no_prenet_fuse", and the opt-in "attn_sub"

@@ -98,6 +98,11 @@ struct ge2e_handle_s {
     int overlap = 1;                       // GE2E_NO_OVERLAP=1 turns the side stream off
     int num_cus = 0;                       // of the handle's device, queried at the first persistent launch
     int device = -1;                       // device of the first GPU call; later calls on another current device are refused
+    // What the latest training forwards left in their workspaces that the backward's kernel choice depends on (options are read at
+    // every call and may change between a forward and its backward): did the FFN leave its ReLU / dropout mask as bits?
+    struct FwdNote { const void* ws = nullptr; bool bits = false; };
+    FwdNote fwd_notes[8];
+    int fwd_note_next = 0;
 };
 
 namespace {
@@ -456,6 +461,18 @@ int gemm_ln(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
 // FFN1 -> ReLU -> dropout -> FFN2 -> dropout -> residual -> LayerNorm in one launch (ffn.cuh): 16-bit modes, full-height layers.
 // The choice never depends on M (a row's result must not depend on the batch it sits in): every non-last layer takes it.
 inline bool ffn_chain_on() { return !opt(O_NO_FFN_CHAIN); }
+inline void note_forward(ge2e_handle h, const void* ws, bool bits) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (auto& n : h->fwd_notes) if (n.ws == ws) { n.bits = bits; return; }
+    h->fwd_notes[h->fwd_note_next] = {ws, bits};
+    h->fwd_note_next = (h->fwd_note_next + 1) % 8;
+}
+// the backward's view: the note of this workspace's forward, or (more than 8 forwards ago) the option as it stands now
+inline bool forward_left_bits(ge2e_handle h, const void* ws) {
+    std::lock_guard<std::mutex> g(h->mu);
+    for (auto& n : h->fwd_notes) if (n.ws == ws) return n.bits;
+    return ffn_chain_on();
+}
 template <typename T>
 int launch_ffn_chain(ge2e_handle h, hipStream_t st, const FfnArgs& a) {
     if constexpr (sizeof(T) != 2) return fail(h, GE2E_EUNSUPPORTED, "ffn chain: 16-bit modes only");
@@ -903,6 +920,8 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         GE2E_LAUNCH(h, transpose_f32_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
                     P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
     }
+    const bool ffn_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && ffn_chain_on();     // read ONCE per forward
+    if (train) note_forward(h, ws, ffn_chained);
     // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
     if (mel_f16) {
         auto kern = mel_pack_kernel<T, _Float16>;
@@ -975,7 +994,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             CK((gemm_ln<T, X3>(h, st, a)));
         }
         }
-        if (sizeof(T) == 2 && !last && c.ffn == FFN_F && d == 256 && ffn_chain_on()) {
+        if (!last && ffn_chained) {
             // linear1 + ReLU + dropout + linear2 + dropout2 + residual + norm2, the hidden on chip (written once in train mode)
             FfnArgs a{};
             a.A = ws + L.h1[l]; a.lda = d; a.W1 = ws + L.w_l1[l]; a.b1 = P[lp(l, L_L1_B)]; a.W2 = ws + L.w_l2[l]; a.b2 = P[lp(l, L_L2_B)];
@@ -1061,6 +1080,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     // go to the END of the main chain, which otherwise idles ~170 us while the weight-gradient stream finishes (step 3.569 -> 3.541 ms;
     // option no_colsum_end keeps them on the weight-gradient stream, as deeper stacks and runs with bucket callbacks -- whose layer buckets
     // would have to be split -- do anyway)
+    // options are read ONCE per backward; what the forward left in this workspace comes from its note, not from the options as they stand now
+    const bool fwd_bits = forward_left_bits(h, ws), use_bits = maskbits_on(), chain_bwd_opt = ffn_chain_bwd_on();
     const int stop_after = opt(O_DEBUG_BWD_STOP);        // diagnostics only: >= 0 returns after k layers so ge2e_debug_tap sees that layer's scratch
     const bool defer_colsum = !opt(O_NO_COLSUM_END) && !cb && c.layers <= 3 && stop_after < 0;   // (a stopped backward never reaches its end)
     LnBwdArgs deferred[8]; int ndeferred = 0;
@@ -1091,7 +1112,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         // norm2 backward + dF + dH1 as ONE launch (ffn.cuh, BWD): full-size layers of the 16-bit modes whose forward left the mask bits
         auto uses_chain_bwd = [&](int ll) {
             if constexpr (sizeof(T) != 2) return false;
-            else return ll >= 0 && ll < c.layers - 1 && L.fbits[ll] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && maskbits_on() && ffn_chain_bwd_on();
+            else return ll >= 0 && ll < c.layers - 1 && L.fbits[ll] != (size_t)-1 && c.ffn == FFN_F && d == 256 && fwd_bits && use_bits && chain_bwd_opt;
         };
         const bool chain_bwd = uses_chain_bwd(l);
         // (a larger wgrad_ks share for the products of the layer processed last -- 208 / 256 blocks -- was measured in round 3: no effect)
@@ -1156,7 +1177,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             sc.arm();
             // a layer whose forward went through the chained FFN kernel left the mask as bits: 1/16 of the bytes of the hidden
             bool bits = false;
-            if constexpr (sizeof(T) == 2) bits = L.fbits[l] != (size_t)-1 && c.ffn == FFN_F && d == 256 && ffn_chain_on() && ws_shape(a) && maskbits_on();
+            if constexpr (sizeof(T) == 2) bits = L.fbits[l] != (size_t)-1 && c.ffn == FFN_F && d == 256 && fwd_bits && ws_shape(a) && use_bits;
             if (bits) {
                 a.R = ws + L.fbits[l]; a.ldr = c.ffn / 8;
                 if constexpr (sizeof(T) == 2) CK((launch_gemm_ws<T, EPI_MASKBITS>(h, st, a)));

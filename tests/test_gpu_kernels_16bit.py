@@ -271,3 +271,37 @@ def test_fused_attention_sublayer_matches_its_three_launches(prec, n, t):
     assert (a["h1.0"] - b["h1.0"]).abs().max() <= 2 * ulp * a["h1.0"].abs().max()
     assert ((a["h1.0"] != b["h1.0"]).float().mean()) < 0.02              # a handful of single-ulp flips
     assert tp.rel_l2(b["h2.1"].cpu().numpy(), a["h2.1"].cpu().numpy()) < 5e-3 and tp.rel_l2(b["emb"].cpu().numpy(), a["emb"].cpu().numpy()) < 5e-3
+
+
+@pytest.mark.parametrize("first", [0, 1])
+def test_option_flipped_between_forward_and_backward(first):
+    """Options are read at every call; what a forward LEFT in its workspace (the FFN's ReLU / dropout mask as bits, or not) is noted by the forward and
+    read back by its backward, so flipping `no_ffn_chain` in between must not make the backward read bits that were never written: the gradients
+    are those of the run whose forward had the same setting (same kernels on the forward side; the backward side may differ by the dF kernel's rounding)."""
+    from speaker_embedding_torch_amd import _lib
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    import test_gpu_parity as tp
+    n, t = 12, 96
+    x = torch.from_numpy(O.formula_mel(17, n, 80, t, logmel=True)).cuda()
+
+    def run(flip):
+        _lib.set_option("no_ffn_chain", first)
+        try:
+            m, _, _ = tp.build(GE2E, "bf16", 0.1)
+            m.train()
+            m._step = 0
+            emb = m(x)
+            loss = GE2E_Loss().cuda()(emb, 3)
+            torch.cuda.synchronize()
+            if flip:
+                _lib.set_option("no_ffn_chain", 1 - first)
+            loss.backward()
+            torch.cuda.synchronize()
+            return {k: p.grad.detach().float().cpu().numpy().copy() for k, p in m.named_parameters()}
+        finally:
+            _lib.set_option("no_ffn_chain", 0)
+
+    a, b = run(False), run(True)
+    for k in a:
+        if a[k].size > 1:
+            assert tp.rel_l2(b[k], a[k]) < 2e-2, (k, tp.rel_l2(b[k], a[k]))
