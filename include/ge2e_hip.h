@@ -213,7 +213,7 @@ int ge2e_debug_tap(ge2e_handle h, const char* name, int n_utts, int frames, int 
  * forward's own record, so an option may change between a forward and its backward.  Names
  * (ge2e_option_name(0 .. ) enumerates them, NULL past the end): kernel-selection ablations "no_overlap", "no_ws_gemm", "no_kl_gemm",
  * "no_lnfuse", "no_sk_gemm", "no_ffn_chain", "ffn_wv" (4 | 8), "no_ffn_chain_bwd", "no_wgrad_ks", "no_reduce_batch",
- * "wgrad_ks_blocks" (n), "no_event_bind", "no_maskbits", "no_colsum_end", "no_prenet_fuse", and the opt-in "attn_sub"
+ * "wgrad_ks_blocks" (n), "no_event_bind", "no_maskbits", "no_colsum_end", "no_prenet_fuse", "no_last_chain", and the opt-in "attn_sub"
  * (1: the attention sub-layer of a full layer as one launch per utterance; measured slower than its three launches, default 0); test hooks
  * "debug_bwd_stop" (k >= 0: a backward returns after k layers so that ge2e_debug_tap shows that layer's scratch; -1 off) and
  * "debug_side_delay_us" (hold the weight-gradient stream back after every fork).  Unknown name: GE2E_EINVAL.

@@ -25,6 +25,7 @@
 #include "gemm_kl.cuh"
 #include "gemm_sk.cuh"
 #include "ffn.cuh"
+#include "lastc.cuh"
 #include "wgrad_ks.cuh"
 #include "misc.cuh"
 #include "melfront.cuh"
@@ -46,7 +47,7 @@ struct ParamInfo { std::string name; int64_t numel, offset; };
 // The ctypes loader forwards GE2E_<NAME> environment variables here only when GE2E_DEV_SWITCHES=1 (tools/ab.sh, tools/switch_test.sh).
 enum Opt {
     O_NO_OVERLAP, O_NO_WS_GEMM, O_NO_KL_GEMM, O_NO_LNFUSE, O_NO_SK_GEMM, O_NO_FFN_CHAIN, O_FFN_WV, O_NO_FFN_CHAIN_BWD, O_NO_WGRAD_KS,
-    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE, O_ATTN_SUB,
+    O_NO_REDUCE_BATCH, O_WGRAD_KS_BLOCKS, O_NO_EVENT_BIND, O_NO_MASKBITS, O_NO_COLSUM_END, O_NO_PRENET_FUSE, O_NO_LAST_CHAIN, O_ATTN_SUB,
     O_DEBUG_BWD_STOP, O_DEBUG_SIDE_DELAY_US, O_COUNT
 };
 struct OptDef { const char* name; int def; };
@@ -66,6 +67,7 @@ constexpr OptDef OPT_DEFS[O_COUNT] = {
     {"no_maskbits", 0},         // dF reads the stored hidden as its mask
     {"no_colsum_end", 0},       // norm2 column sums on the weight-gradient stream
     {"no_prenet_fuse", 0},      // prenet backward as recompute GEMM + weight-gradient launch
+    {"no_last_chain", 0},       // the last layer after its attention + the tail as five / six launches instead of one each way (lastc.cuh)
     {"attn_sub", 0},            // 1: in_proj, attention, out_proj + LayerNorm of a full layer as ONE launch per utterance (attn_sub.cuh; measured slower, off)
     {"debug_bwd_stop", -1},     // >= 0: backward returns after k layers (parity tests read that layer's scratch through ge2e_debug_tap)
     {"debug_side_delay_us", 0}, // tests: hold the weight-gradient stream back after every fork
@@ -762,6 +764,19 @@ int launch_attn_sub(ge2e_handle h, hipStream_t st, const AttnSubArgs& a, int n) 
 }
 
 // last layer: one query per utterance, no K / V projection (attn_last.cuh)
+// the compact chain of the last layer + the tail (lastc.cuh): what forward and backward share
+inline LastcArgs lastc_args(const ge2e_config& c, const Layout& L, unsigned char* ws, const float* const* P, int l, int n, int t, const void* hin) {
+    LastcArgs a{};
+    a.n = n; a.drow_mul = t; a.eps = c.ln_eps;
+    a.o = ws + L.o[l]; a.x0 = hin; a.ldx = c.emb * t;
+    a.Wo = ws + L.w_out[l]; a.bo = P[lp(l, L_OUT_B)]; a.g1 = P[lp(l, L_N1_W)]; a.be1 = P[lp(l, L_N1_B)];
+    a.W1 = ws + L.w_l1[l]; a.b1 = P[lp(l, L_L1_B)]; a.W2 = ws + L.w_l2[l]; a.b2 = P[lp(l, L_L2_B)]; a.g2 = P[lp(l, L_N2_W)]; a.be2 = P[lp(l, L_N2_B)];
+    a.gf = P[p_fn_w(c)]; a.bf = P[p_fn_b(c)]; a.wq = P[p_proj_w(c)]; a.bq = P[p_proj_b(c)];
+    a.h1 = ws + L.h1[l]; a.f = ws + L.f[l]; a.h2 = ws + L.h2[l];
+    a.xhat = (float*)(ws + L.xhat_f); a.rstd_f = (float*)(ws + L.rstd_f); a.zm = (float*)(ws + L.zm); a.nrm = (float*)(ws + L.nrm);
+    a.emb = (float*)(ws + L.emb_keep);
+    return a;
+}
 inline AttnLastArgs attn_last_args(const ge2e_config& c, const Layout& L, unsigned char* ws, const float* const* P, int l, int t, const void* x,
                                    bool train, const Drop& drop) {
     AttnLastArgs a{};
@@ -921,6 +936,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
                     P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
     }
     const bool ffn_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && ffn_chain_on();     // read ONCE per forward
+    const bool last_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && samples == 1 && !opt(O_NO_LAST_CHAIN);
     if (train) note_forward(h, ws, ffn_chained);
     // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
     if (mel_f16) {
@@ -975,6 +991,19 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             ProfScope ps(h, st, GE2E_K_ATTN_FWD, 4.0 * t * 256.0 * 4.0 * n, (double)n * t * d * sizeof(T));
             auto kern = attn_last_fwd_kernel<T>;
             GE2E_LAUNCH(h, kern, dim3(n), dim3(256), attn_last_fwd_smem(t), st, a);
+        }
+        if (last && last_chained) {
+            // out_proj + norm1, the FFN + norm2, transformer.norm, projection and F.normalize of the compact rows in ONE launch (lastc.cuh)
+            if constexpr (sizeof(T) == 2) {
+                LastcArgs a = lastc_args(c, L, ws, P, l, n, t, hin);
+                a.rstd1 = train ? (float*)(ws + L.rstd1[l]) : nullptr; a.rstd2 = train ? (float*)(ws + L.rstd2[l]) : nullptr;
+                a.emb_out = out_emb;
+                a.d_sa = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.d_fh = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
+                a.d_ff = make_drop(train, c.tf_dropout, seed, step, site_ff(l));
+                auto kern = lastc_fwd_kernel<T, LASTC_NW>;
+                GE2E_LAUNCH(h, kern, dim3((n + 15) / 16), dim3(LASTC_THREADS), lastc_smem<LASTC_NW>(), st, a);
+            }
+            return 0;
         }
         if (!last) {   // softmax(q k^T / 8) v per (utterance, head)
             AttnArgs a{};
@@ -1085,6 +1114,30 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
     const int stop_after = opt(O_DEBUG_BWD_STOP);        // diagnostics only: >= 0 returns after k layers so ge2e_debug_tap sees that layer's scratch
     const bool defer_colsum = !opt(O_NO_COLSUM_END) && !cb && c.layers <= 3 && stop_after < 0;   // (a stopped backward never reaches its end)
     LnBwdArgs deferred[8]; int ndeferred = 0;
+    // the last layer below its attention + the tail as ONE launch (lastc.cuh); what it replaces is skipped in the layer loop
+    const bool last_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && samples == 1 && !opt(O_NO_LAST_CHAIN);
+    if (last_chained) {
+        if constexpr (sizeof(T) == 2) {
+            const int l = c.layers - 1;
+            LastcArgs a = lastc_args(c, L, ws, P, l, n, t, nullptr);
+            a.rstd1 = (float*)(ws + L.rstd1[l]); a.rstd2 = (float*)(ws + L.rstd2[l]);
+            a.d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l)); a.d_fh = make_drop(true, c.tf_dropout, seed, step, site_ffh(l));
+            a.d_ff = make_drop(true, c.tf_dropout, seed, step, site_ff(l));
+            a.d_emb = d_emb; a.wqT = (const float*)(ws + L.wqT); a.W2T = ws + L.w_l2T[l]; a.W1T = ws + L.w_l1T[l]; a.WoT = ws + L.w_outT[l];
+            a.d_raw = (float*)(ws + L.d_raw);
+            a.dH = ws + L.c_dH; a.dP = ws + L.c_dP; a.dM = ws + L.c_dM; a.dF = ws + L.c_dF; a.dHb = ws + L.c_dHb;
+            a.dP2 = ws + L.c_dP2; a.dM2 = ws + L.c_dM2; a.dO = ws + L.c_dO;
+            a.dgf = G(p_fn_w(c)); a.dbf = G(p_fn_b(c)); a.dg2 = G(lp(l, L_N2_W)); a.db2 = G(lp(l, L_N2_B)); a.dg1 = G(lp(l, L_N1_W)); a.db1 = G(lp(l, L_N1_B));
+            auto kern = lastc_bwd_kernel<T, LASTC_NW>;
+            sc.arm();
+            GE2E_LAUNCH(h, kern, dim3((n + 15) / 16), dim3(LASTC_THREADS), lastc_smem<LASTC_NW>(), st, a);
+            sc.fork();                                    // everything below on the weight-gradient stream until the attention: the four small weight gradients
+            TailArgs w{};
+            w.T = 1; w.samples = samples; w.N = n; w.zm = (float*)(ws + L.zm); w.d_raw = (float*)(ws + L.d_raw);
+            w.dwq = G(p_proj_w(c)); w.dbq = G(p_proj_b(c));
+            GE2E_LAUNCH(h, tail_wgrad_kernel, dim3(d, std::max(1, std::min(16, (n / samples + 31) / 32))), dim3(256), 0, wst, w);
+        }
+    } else
     {
         TailArgs a{};
         a.T = 1 /* compact rows */; a.samples = samples; a.N = n;
@@ -1147,7 +1200,9 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         const Drop d_sa = make_drop(true, c.tf_dropout, seed, step, site_sa(l));
         if (!last) sc.wait(g_set1[bs]);                  // (the last layer's compact scratch is written once per backward)
         unsigned char* gm = d_ff.thr ? b_dM : b_dP;
-        if (chain_bwd) {
+        const bool chained_here = last && last_chained;  // lastc_bwd_kernel left dM, dF, dM2, dP2, dO; only the weight gradients remain (the side stream is forked)
+        if (chained_here) {
+        } else if (chain_bwd) {
             if constexpr (sizeof(T) == 2) {
                 sc.wait(g_dF[bs]);
                 FfnArgs a{};
@@ -1185,7 +1240,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((gemm128<T, EPI_MASK, ALOAD_ROW, X3>(h, st, a)));
         }
         }
-        sc.fork();
+        if (!chained_here) sc.fork();
         {   // (started right after norm2's backward instead, next to the dF GEMM that streams the same gm and f: no gain, 4.10 vs 4.10 ms)
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.f[l]; a.ldx = c.ffn; a.dW = G(lp(l, L_L2_W)); a.ldw = c.ffn; a.db = G(lp(l, L_L2_B));
@@ -1200,7 +1255,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             CK((launch_wgrad<T, ALOAD_ROW, X3>(h, wst, a, wpart, &pend)));
             if (!last) g_dF[bs] = sc.mark();
         }
-        if (!chain_bwd) {   // dH1 = dPre2 + dF W1
+        if (!chain_bwd && !chained_here) {   // dH1 = dPre2 + dF W1
             GemmArgs a{};
             a.A = b_dF; a.lda = c.ffn; a.W = ws + L.w_l1T[l]; a.ldw = c.ffn; a.C = b_dHb; a.ldc = d;
             a.M = Rl; a.N = d; a.K = c.ffn; a.R = b_dP; a.ldr = d;
@@ -1212,6 +1267,8 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         GemmArgs ado{};        // dO = dA Wo
         ado.A = gm; ado.lda = d; ado.W = ws + L.w_outT[l]; ado.ldw = d; ado.C = b_dO; ado.ldc = d;
         ado.M = Rl; ado.N = d; ado.K = d;
+        if (chained_here) {
+        } else {
         sc.arm();
         if (ws_epilogue<T, EPI_MASK>() && ws_shape(ado) && lnfuse_on()) {
             // norm1 backward rides in the prologue of the dO GEMM
@@ -1234,6 +1291,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
         CK((gemm128<T, EPI_NONE, ALOAD_ROW, X3>(h, st, ado)));
         }
         sc.fork();
+        }
         {
             WgradArgs a{};
             a.Y = gm; a.ldy = d; a.X = ws + L.o[l]; a.ldx = d; a.dW = G(lp(l, L_OUT_W)); a.ldw = d; a.db = G(lp(l, L_OUT_B));
