@@ -908,9 +908,12 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
     if (!prepared) {
         std::vector<PrepJob> jobs;
         auto add = [&](const float* src, size_t dst, size_t dstT, int rows, int cols, int ldd) {
-            PrepJob j{src, ws + dst, (train && dstT != (size_t)-1) ? ws + dstT : nullptr, rows, cols, ldd, 0, (ldd + 31) / 32};
+            PrepJob j{src, ws + dst, (train && dstT != (size_t)-1) ? ws + dstT : nullptr, rows, cols, ldd, 0, (ldd + 31) / 32, 0, nullptr};
             jobs.push_back(j);
         };
+        // the two fp32 transposes ride in the same launch: the positional table pe [D][max_pos] -> pe_t [T][D] and projection.weight -> its transpose
+        jobs.push_back(PrepJob{pe, nullptr, nullptr, d, t, t, 0, (t + 31) / 32, c.max_position, (float*)(ws + L.pe_t)});
+        jobs.push_back(PrepJob{P[p_proj_w(c)], nullptr, nullptr, d, d, d, 0, (d + 31) / 32, 0, (float*)(ws + L.wqT)});
         add(P[P_PRENET_W], L.w_prenet, (size_t)-1, d, c.mel_dim, L.KP);
         for (int l = 0; l < c.layers; ++l) {
             add(P[lp(l, L_IN_W)], L.w_in[l], L.w_inT[l], 3 * d, d, d);
@@ -930,10 +933,6 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             auto kern = prep_weights_kernel<T>;
             GE2E_LAUNCH(h, kern, dim3(tiles), dim3(256), 0, st, a);
         }
-        GE2E_LAUNCH(h, transpose_f32_kernel, dim3((t + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
-                    pe, (float*)(ws + L.pe_t), d, c.max_position, t);
-        GE2E_LAUNCH(h, transpose_f32_kernel, dim3((d + 31) / 32, (d + 31) / 32), dim3(256), 0, st,
-                    P[p_proj_w(c)], (float*)(ws + L.wqT), d, d, d);
     }
     const bool ffn_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && ffn_chain_on();     // read ONCE per forward
     const bool last_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && samples == 1 && !opt(O_NO_LAST_CHAIN);
@@ -941,10 +940,10 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
     // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
     if (mel_f16) {
         auto kern = mel_pack_kernel<T, _Float16>;
-        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, (const _Float16*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
+        GE2E_LAUNCH(h, kern, dim3((t + 63) / 64, n), dim3(256), 0, st, (const _Float16*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
     } else {
         auto kern = mel_pack_kernel<T, float>;
-        GE2E_LAUNCH(h, kern, dim3((t + 31) / 32, L.KP / 32, n), dim3(256), 0, st, (const float*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
+        GE2E_LAUNCH(h, kern, dim3((t + 63) / 64, n), dim3(256), 0, st, (const float*)mel, (T*)(ws + L.xt), c.mel_dim, t, L.KP);
     }
     // ---- prenet + ReLU + positional encoding (+ dropout)
     {

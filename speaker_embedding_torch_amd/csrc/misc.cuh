@@ -10,10 +10,12 @@ namespace ge2e {
 // weight preparation: fp32 master [rows][cols] -> T [rows][ldd] (zero padded) and T^T [cols][rows]
 // ---------------------------------------------------------------------------------------------
 struct PrepJob {
-    const float* src; void* dst; void* dstT;
+    const float* src; void* dst; void* dstT;     // dst / dstT may be null
     int rows, cols, ldd;        // ldd >= cols
     int tile0;                  // first 32x32 tile index of this job
     int tiles_x;                // tiles along the (padded) column dim
+    int lds;                    // source row stride in floats (0: cols)
+    float* dstT32;              // fp32 transposed copy [cols][rows], or null (the positional table pe [D][max_pos] -> pe_t [T][D]; Wq -> Wq^T)
 };
 constexpr int PREP_MAX_JOBS = 16;
 struct PrepArgs { PrepJob job[PREP_MAX_JOBS]; int njobs; };
@@ -30,9 +32,9 @@ __global__ void __launch_bounds__(256) prep_weights_kernel(const PrepArgs a) {
 #pragma unroll
     for (int r = ly; r < 32; r += 8) {
         const int row = ty * 32 + r, col = tx * 32 + lx;
-        const float v = (row < jb.rows && col < jb.cols) ? jb.src[(size_t)row * jb.cols + col] : 0.0f;
+        const float v = (row < jb.rows && col < jb.cols) ? jb.src[(size_t)row * (jb.lds ? jb.lds : jb.cols) + col] : 0.0f;
         tile[r][lx] = v;
-        if (row < jb.rows && col < jb.ldd) ((T*)jb.dst)[(size_t)row * jb.ldd + col] = from_f32<T>(v);
+        if (jb.dst && row < jb.rows && col < jb.ldd) ((T*)jb.dst)[(size_t)row * jb.ldd + col] = from_f32<T>(v);
     }
     __syncthreads();
     if (jb.dstT) {
@@ -42,40 +44,43 @@ __global__ void __launch_bounds__(256) prep_weights_kernel(const PrepArgs a) {
             if (row < jb.rows && col < jb.cols) ((T*)jb.dstT)[(size_t)col * jb.rows + row] = from_f32<T>(tile[lx][r]);
         }
     }
-}
-
-// fp32 [rows][cols] -> fp32 transposed [take][rows]: pe buffer [D][max_pos] -> pe_t [T][D]; Wq -> Wq^T
-__global__ void __launch_bounds__(256) transpose_f32_kernel(const float* src, float* dst, int rows, int cols, int take) {
-    __shared__ float tile[32][33];
-    const int tx = blockIdx.x, ty = blockIdx.y, lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    for (int r = ly; r < 32; r += 8) {
-        const int row = ty * 32 + r, col = tx * 32 + lx;
-        tile[r][lx] = (row < rows && col < cols) ? src[(size_t)row * cols + col] : 0.0f;
-    }
-    __syncthreads();
-    for (int r = ly; r < 32; r += 8) {
-        const int col = tx * 32 + r, row = ty * 32 + lx;
-        if (row < rows && col < take) dst[(size_t)col * rows + row] = tile[lx][r];
+    if (jb.dstT32) {
+#pragma unroll
+        for (int r = ly; r < 32; r += 8) {
+            const int col = tx * 32 + r, row = ty * 32 + lx;
+            if (row < jb.rows && col < jb.cols) jb.dstT32[(size_t)col * jb.rows + row] = tile[lx][r];
+        }
     }
 }
 
 // mel batch fp32 [N][mel][T] (channels-first, contiguous along T) -> row-major T-typed [N*T][KP], zero beyond mel.
-// One coalesced streaming pass (reads along t, writes along k through a 32x32 LDS tile); afterwards the prenet
-// forward, its backward and its weight gradient all use the ordinary row loaders.  grid = (ceil(T/32), KP/32, N)
-// TI = float (the reference collater's dtype) or _Float16 (patterns are fp16 on disk: half the host-to-device bytes)
+// One coalesced streaming pass; afterwards the prenet forward, its backward and its weight gradient all use the ordinary row loaders.
+// A block turns 64 frames of one utterance: reads run along t (256 bytes per mel row), every output row leaves as KP * sizeof(T) contiguous
+// bytes in 16-byte (fp32: 32-byte) pieces (round 4; the 32 x 32-tile form wrote 64-byte pieces: 32 -> 2x us at 960 x 160).
+// grid = (ceil(T / 64), N); KP <= 128, KP % 8 == 0.  TI = float (the reference collater's dtype) or _Float16 (patterns are fp16 on disk: half
+// the host-to-device bytes)
 template <typename T, typename TI>
 __global__ void __launch_bounds__(256) mel_pack_kernel(const TI* x, T* xt, int mel, int T_, int KP) {
-    __shared__ float tile[32][33];
-    const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32, n = blockIdx.z;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    for (int r = ly; r < 32; r += 8) {
-        const int k = k0 + r, t = t0 + lx;
-        tile[r][lx] = (k < mel && t < T_) ? (float)x[((size_t)n * mel + k) * T_ + t] : 0.0f;
-    }
+    __shared__ float tile[128][65];
+    const int t0 = blockIdx.x * 64, n = blockIdx.y;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    const bool tok = t0 + lx < T_;
+    TI v[32];                                          // all of a thread's loads in flight before the first LDS write
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int k = ly + 4 * j; v[j] = (k < mel && tok) ? x[((size_t)n * mel + k) * T_ + t0 + lx] : (TI)0; }
+#pragma unroll
+    for (int j = 0; j < 32; ++j) { const int k = ly + 4 * j; if (k < KP) tile[k][lx] = (float)v[j]; }
     __syncthreads();
-    for (int r = ly; r < 32; r += 8) {
-        const int t = t0 + r, k = k0 + lx;
-        if (t < T_) xt[((size_t)n * T_ + t) * KP + k] = from_f32<T>(tile[lx][r]);
+    const int kc = (threadIdx.x & 15) * 8, rr = threadIdx.x >> 4;
+    if (kc < KP) {
+#pragma unroll
+        for (int r = rr; r < 64; r += 16) {
+            const int t = t0 + r;
+            if (t >= T_) break;
+            T* dst = xt + ((size_t)n * T_ + t) * KP + kc;
+            store4(dst, tile[kc][r], tile[kc + 1][r], tile[kc + 2][r], tile[kc + 3][r]);
+            store4(dst + 4, tile[kc + 4][r], tile[kc + 5][r], tile[kc + 6][r], tile[kc + 7][r]);
+        }
     }
 }
 

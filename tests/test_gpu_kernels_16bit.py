@@ -305,3 +305,43 @@ def test_option_flipped_between_forward_and_backward(first):
     for k in a:
         if a[k].size > 1:
             assert tp.rel_l2(b[k], a[k]) < 2e-2, (k, tp.rel_l2(b[k], a[k]))
+
+
+@pytest.mark.parametrize("prec,n,t", [("bf16", 20, 96), ("fp16", 37, 160), ("bf16", 16, 50)])
+def test_last_layer_chain_matches_its_separate_launches(prec, n, t):
+    """lastc.cuh (default; option no_last_chain = 1 restores the launches it replaces): the last layer below its attention and the tail -- out_proj +
+    norm1, FFN + norm2, transformer.norm, projection, F.normalize -- as ONE launch on the compact rows, and the same chain backwards as one launch.
+    Same inputs, same dropout stream, train mode, a partial last row tile: the saved tensors agree with the separate launches to a rounding of the
+    storage type (the LayerNorm sums run in another order), the d-vectors and every gradient to the error those roundings propagate."""
+    from speaker_embedding_torch_amd import _lib
+    from speaker_embedding_torch_amd.Modules import GE2E, GE2E_Loss
+    import test_gpu_parity as tp
+    x = torch.from_numpy(O.formula_mel(19, n, 80, t, logmel=True)).cuda()
+    out = {}
+    for mode in (1, 0):
+        _lib.set_option("no_last_chain", mode)
+        try:
+            m, _, _ = tp.build(GE2E, prec, 0.1)
+            m.train()
+            m._step = 0
+            emb = m(x)
+            taps = {k: m.workspace_view(k, n, t, True).float().clone() for k in ("o.2", "h1.2", "f.2", "h2.2")}
+            scale = 1024.0 if prec == "fp16" else 1.0
+            (GE2E_Loss().cuda()(emb, 1 if n % 5 else 5) * scale).backward()
+            torch.cuda.synchronize()
+            out[mode] = (taps, emb.detach().clone(), {k: p.grad.detach().float().cpu().numpy() / scale for k, p in m.named_parameters()})
+        finally:
+            _lib.set_option("no_last_chain", 0)
+    (ta, ea, ga), (tb, eb, gb) = out[1], out[0]
+    assert torch.equal(ta["o.2"], tb["o.2"])                               # the attention above it is the same launch
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    assert (ta["h1.2"] - tb["h1.2"]).abs().max() <= 2 * ulp * ta["h1.2"].abs().max()
+    for k in ("f.2", "h2.2"):
+        assert tp.rel_l2(tb[k].cpu().numpy(), ta[k].cpu().numpy()) < 4 * ulp, k
+    assert tp.rel_l2(eb.cpu().numpy(), ea.cpu().numpy()) < 4 * ulp
+    nb = np.linalg.norm(ga["prenet.bias"])
+    for k in ga:
+        if ga[k].size == 1:
+            assert abs(float(ga[k].ravel()[0] - gb[k].ravel()[0])) < 0.05 * nb, k
+        else:
+            assert tp.rel_l2(gb[k], ga[k]) < (0.05 if prec == "bf16" else 0.01), (k, tp.rel_l2(gb[k], ga[k]))
