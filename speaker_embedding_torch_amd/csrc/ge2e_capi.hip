@@ -369,7 +369,18 @@ constexpr bool ws_epilogue() {
 inline bool ws_shape(const GemmArgs& a) {
     return !opt(O_NO_WS_GEMM) && a.K == 256 && a.N % 256 == 0 && a.M > 0 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0;
 }
-template <typename T, int EPI>
+// Row partitions of the prenet's weight-stationary launch: a multiple of 8 (XCD mapping) and of T / gcd(T, 16) (then every 16-row tile of a block starts
+// at the same frame offset), the multiple nearest 480 blocks; 0 when no such count is <= 1024 (the tiled kernel then takes the product)
+inline int prenet_ws_parts(int t) {
+    if (t <= 0) return 0;
+    auto gcd = [](long long a, long long b) { while (b) { const long long r = a % b; a = b; b = r; } return a; };
+    const long long pd = t / gcd(t, 16), unit = pd / gcd(pd, 8) * 8;
+    if (unit > 1024) return 0;
+    long long k = (480 + unit / 2) / unit; if (k < 1) k = 1;
+    while (k * unit > 1024) --k;
+    return (int)(k * unit);
+}
+template <typename T, int EPI, int KK = 256>
 int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     constexpr bool reads_r = (EPI == EPI_LN || EPI == EPI_MASK);
     if (EPI == EPI_MASKBITS && (a.N % 128 != 0 || a.ldr % 16 != 0)) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: mask-bit rows are whole 16-byte words");
@@ -379,11 +390,12 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     int parts = (512 / cg) / 8 * 8;                       // two resident blocks per CU
     if (parts > (ntiles + 7) / 8 * 8) parts = (ntiles + 7) / 8 * 8;
     if (parts < 8) parts = 8;
+    if constexpr (EPI == EPI_PRENET) parts = prenet_ws_parts(a.T);       // 16 parts a multiple of T (the kernel keeps its positional rows in registers)
     const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0)) +
-                          (EPI == EPI_MASKBITS ? (double)a.M * a.N / 8.0 : 0.0);
+                          (EPI == EPI_MASKBITS || EPI == EPI_PRENET ? (double)a.M * a.N / 8.0 : 0.0);
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
-    auto kern = gemm_ws_kernel<T, EPI, 256>;
-    GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_smem<EPI, 256>()), st, a, parts, ntiles);
+    auto kern = gemm_ws_kernel<T, EPI, KK>;
+    GE2E_LAUNCH(h, kern, dim3(cg * parts), dim3(256), (gemm_ws_smem<EPI, KK>()), st, a, parts, ntiles);
     return 0;
 }
 
@@ -953,7 +965,14 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         a.drop = make_drop(train, c.pe_dropout, seed, step, SITE_PE);
         a.pe_t = (const float*)(ws + L.pe_t); a.alpha = P[P_ALPHA]; a.T = t; a.mel = c.mel_dim;
         a.relu_bits = train ? ws + L.pbits : nullptr;
-        CK((gemm128<T, EPI_PRENET, ALOAD_ROW, X3>(h, st, a)));
+        bool ws_done = false;
+        if constexpr (sizeof(T) == 2) {       // weight-stationary form (K = 128 = the padded mel width): the 64 weight fragments and the block's 16 positional rows in registers
+            if (!opt(O_NO_WS_GEMM) && a.K == 128 && a.N == 256 && a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldc % 8 == 0 && prenet_ws_parts(t) > 0) {
+                CK((launch_gemm_ws<T, EPI_PRENET, 128>(h, st, a)));
+                ws_done = true;
+            }
+        }
+        if (!ws_done) CK((gemm128<T, EPI_PRENET, ALOAD_ROW, X3>(h, st, a)));
     }
     for (int l = 0; l < c.layers; ++l) {
         unsigned char* hin = ws + (l == 0 ? L.h0 : L.h2[l - 1]);

@@ -37,8 +37,8 @@ constexpr int WS_D = 3;        // tiles in flight ahead of the one being consume
 template <int EPI, int K_>
 constexpr size_t gemm_ws_smem() {
     constexpr bool HAS_R = (EPI == EPI_MASK || EPI == EPI_ADD || EPI == EPI_LN);
-    return (size_t)WS_NSTG * 16 * K_ * 2 + (HAS_R ? (size_t)4 * WS_NSTG * 2048 : EPI == EPI_MASKBITS ? (size_t)4 * WS_NSTG * 256 : 0) + 4 * 2048 +
-           (EPI == EPI_LN ? 3 * 1024 + 2 * 4 * 16 * 8 : 0);
+    return (size_t)WS_NSTG * 16 * K_ * 2 + (HAS_R ? (size_t)4 * WS_NSTG * 2048 : EPI == EPI_MASKBITS ? (size_t)4 * WS_NSTG * 256 : 0) +
+           4 * 2048 + (EPI == EPI_LN ? 3 * 1024 + 2 * 4 * 16 * 8 : 0);
 }
 
 // grid = 8 * (N / 256) * (parts / 8) blocks; `parts` (multiple of 8) row partitions, `ntiles` = ceil(M / 16)
@@ -77,6 +77,7 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
     // ---- stationary operand: this wave's 64 weight rows as MFMA fragments
     u32x4 wf[4][KGN];
     f32x4 b4[4];
+    f32x4 ape[4] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};   // EPI_PRENET: alpha pe[frame][this lane's columns]
     {
         const unsigned char* W = (const unsigned char*)p.W;
 #pragma unroll
@@ -84,14 +85,27 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
 #pragma unroll
             for (int kg = 0; kg < KGN; ++kg)
                 wf[nt][kg] = *(const u32x4*)(W + ((size_t)(n0 + nt * 16 + i) * p.ldw + kg * 32 + g * 8) * 2);
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP) b4[nt] = *(const f32x4*)(p.bias + n0 + nt * 16 + 4 * g);
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DROP || EPI == EPI_PRENET) b4[nt] = *(const f32x4*)(p.bias + n0 + nt * 16 + 4 * g);
             else b4[nt] = f32x4{0, 0, 0, 0};
         }
         if constexpr (EPI == EPI_LN) {          // N == 256: the block holds whole rows; per-column constants live in LDS
             Ls[tid] = p.bias[tid]; Ls[256 + tid] = p.gamma[tid]; Ls[512 + tid] = p.beta[tid];
             __syncthreads();                     // no DMA is in flight yet: an ordinary barrier
         }
+        if constexpr (EPI == EPI_PRENET) {
+            // alpha pe[frame of row i] for this lane's 16 columns, in registers for the block's whole life: the launcher chooses `parts` so that
+            // 16 parts is a multiple of T -- every tile of a block then starts at the same frame offset: (16 (part + j parts) + i) % T = (16 part + i) % T
+            const float al = *p.alpha;
+            const int frame = (int)(((long long)16 * part + i) % p.T);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const f32x4 pe4 = *(const f32x4*)(p.pe_t + (size_t)frame * p.N + n0 + nt * 16 + 4 * g);
+                ape[nt] = f32x4{al * pe4[0], al * pe4[1], al * pe4[2], al * pe4[3]};
+            }
+        }
         // retire these ordinary loads before the first DMA: the compiler's own waits stay out of the loop
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(ape[nt]));
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -206,6 +220,8 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
             }
         } else
         // ---- wave-private epilogue: 16 rows x 64 columns
+        {
+        [[maybe_unused]] unsigned long long sbits = 0ull;     // EPI_PRENET: this lane's sign nibbles of the wave's 64 columns of the row
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             f32x4 v = acc[nt] + b4[nt];
@@ -213,6 +229,15 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
             // staged 16 x 128 B slab, 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7); this lane: chunk 2nt + (g >> 1), half g & 1
             const int so = i * 128 + (((2 * nt + (g >> 1)) ^ ((i >> 1) & 7)) << 4) + (g & 1) * 8;
             if constexpr (EPI == EPI_BIAS_RELU_DROP) (void)relu_drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
+            if constexpr (EPI == EPI_PRENET) {      // h0 = drop(relu(x Wp^T + b) + alpha pe[frame]); the pre-activation's signs leave as bits for the backward
+                if (p.relu_bits) {
+                    const unsigned nib = (unsigned)(v[0] > 0.0f) | ((unsigned)(v[1] > 0.0f) << 1) | ((unsigned)(v[2] > 0.0f) << 2) | ((unsigned)(v[3] > 0.0f) << 3);
+                    sbits |= (unsigned long long)nib << (16 * nt + 4 * g);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f) + ape[nt][r];
+                drop_apply4(p.drop, (uint32_t)row * drm * (uint32_t)p.N + (uint32_t)col, v);
+            }
             if constexpr (EPI == EPI_MASK) {
                 const f32x4 m4 = load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
 #pragma unroll
@@ -229,6 +254,16 @@ __global__ void __launch_bounds__(256) gemm_ws_kernel(const GemmArgs p, const in
             }
             if constexpr (EPI == EPI_ADD) v += load4((const T*)(Rs + (wave * NSTG + s) * 2048 + so));
             store4((T*)(Ow + so), v[0], v[1], v[2], v[3]);
+        }
+        if constexpr (EPI == EPI_PRENET) {
+            if (p.relu_bits) {      // (wave-uniform) the four lanes of a row hold disjoint nibbles: OR them, one 8-byte store per row.  (The counted waits
+                                    // do not count this store: a wave past M skips it, and a count may be too small, never too large)
+                unsigned lo = (unsigned)sbits, hi = (unsigned)(sbits >> 32);
+                lo |= __shfl_xor(lo, 16, 64); lo |= __shfl_xor(lo, 32, 64);
+                hi |= __shfl_xor(hi, 16, 64); hi |= __shfl_xor(hi, 32, 64);
+                if (g == 0 && row < p.M) *(u32x2*)(p.relu_bits + (size_t)row * (p.N / 8) + n0 / 8) = u32x2{lo, hi};
+            }
+        }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
