@@ -20,6 +20,9 @@
 #include "attn_last.cuh"
 #include "attn_sub.cuh"
 #include "prenet_bwd.cuh"
+#ifndef PB_NS
+#define PB_NS 3
+#endif
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
@@ -1386,16 +1389,14 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             a.dH0 = dH0; a.X = ws + L.xt; a.ldx = L.KP; a.bits = ws + L.pbits; a.pe_t = (const float*)(ws + L.pe_t);
             a.dW = G(P_PRENET_W); a.ldw = c.mel_dim; a.db = G(P_PRENET_B); a.dalpha = G(P_ALPHA);
             a.R = R; a.K = c.mel_dim; a.T = t; a.drop = make_drop(true, c.pe_dropout, seed, step, SITE_PE);
-            int splits = 256;
-            const int max_splits = (R + 4 * RS - 1) / (4 * RS);
-            splits = std::max(1, std::min(splits, max_splits));
-            int rps = (R + splits - 1) / splits;
-            rps = (rps + RS - 1) / RS * RS;
-            splits = (R + rps - 1) / rps;
-            a.rows_per_split = rps;
+            // blocks per column tile: ~256, a multiple of T / gcd(T, RS) (every stage of a block then starts at the same frame; T <= max_position keeps it <= 1024)
+            int g2 = t, b2 = RS; while (b2) { const int r2 = g2 % b2; g2 = b2; b2 = r2; }
+            const int pd = t / g2;
+            const int splits = pd * std::max(1, (256 + pd / 2) / pd);
+            a.nsplit = splits;
             const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
             ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R * d * c.mel_dim, (double)R * (d + L.KP) * sizeof(T) + (double)R * d / 8 + 4.0 * d * c.mel_dim);
-            auto kern = prenet_bwd_kernel<T>;
+            auto kern = prenet_bwd_kernel<T, PB_NS>;
             GE2E_LAUNCH(h, kern, dim3(2 * splits), dim3(256), smem, st, a);
         } else {
         GemmArgs a{};

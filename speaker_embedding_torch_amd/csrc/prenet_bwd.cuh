@@ -23,7 +23,8 @@ struct PrenetBwdArgs {
     float* db;                   // [256]
     float* dalpha;               // scalar
     int R, K;                    // rows; K = mel (dW columns written)
-    int rows_per_split, T;
+    int nsplit, T;               // blocks per column tile; block `split` takes the 64-row stages split, split + nsplit, ...: RS nsplit is a multiple of T, so a
+                                 // thread sees the same FRAME at the same position in every one of its stages (dalpha: see the kernel)
     Drop drop;                   // the positional encoding's dropout (counter row * 256 + col)
 };
 
@@ -44,16 +45,17 @@ __global__ void __launch_bounds__(256) prenet_bwd_kernel(const PrenetBwdArgs p) 
     const int L = xcd_remap(blockIdx.x, gridDim.x);
     const int tile = L & 1, split = L >> 1;                 // two 128-column tiles of the 256 output rows, one k tile
     const int n0 = tile * 128;
-    const int rbeg = split * p.rows_per_split;
-    const int rend = min(p.R, rbeg + p.rows_per_split);
-    const int nst = (rend - rbeg + RS - 1) / RS;
+    const int rend = p.R;
+    const int nstg = (p.R + RS - 1) / RS;                   // stages of the whole batch
+    const int nst = split < nstg ? (nstg - split + p.nsplit - 1) / p.nsplit : 0;      // ... of this block: split, split + nsplit, ...
     if (nst <= 0) return;
+    auto row0 = [&](int st) { return (split + st * p.nsplit) * RS; };
 
     constexpr int NS = NS_;
     u32x4 rY[NS][NCH], rX[NS][NCH];
     unsigned rB[NS][NCH];
     auto load_stage = [&](int st, u32x4* ry, u32x4* rx, unsigned* rb) {
-        const int r0 = rbeg + st * RS;
+        const int r0 = row0(st);
         const unsigned char* Y = (const unsigned char*)p.dH0;
         const unsigned char* X = (const unsigned char*)p.X;
 #pragma unroll
@@ -65,26 +67,31 @@ __global__ void __launch_bounds__(256) prenet_bwd_kernel(const PrenetBwdArgs p) 
             rb[q] = ok ? (unsigned)p.bits[(size_t)gr * 32 + ((n0 + c * FR) >> 3)] : 0u;
         }
     };
-    float dal = 0.0f;
+    // dalpha = sum dD o pe[frame]: a thread meets the same (frame, columns) at chunk q of every stage (RS nsplit % T == 0), so it sums dD per
+    // position and multiplies by pe ONCE at the end (the positional rows fetched per chunk were 8 of the stage loop's 20 memory instructions)
+    float sD[NCH][FR];
+#pragma unroll
+    for (int q = 0; q < NCH; ++q)
+#pragma unroll
+        for (int e = 0; e < FR; ++e) sD[q][e] = 0.0f;
     // Y chunk -> dZ chunk: dropout' (the same hash as the forward), dalpha's terms, then the ReLU mask
     auto store_stage = [&](int buf, int st, const u32x4* ry, const u32x4* rx, const unsigned* rb) {
         unsigned char* y = Ys + buf * RS * LD;
         unsigned char* x = Xs + buf * RS * LD;
-        const int r0 = rbeg + st * RS;
+        const int r0 = row0(st);
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
             const int id = tid + 256 * q, row = id / CPR, c = id % CPR, gr = r0 + row;
             const int col = n0 + c * FR;
             const unsigned bits = rb[q] >> (col & 7);        // fp32: 4 columns per chunk = one nibble of the byte
             const T* src = (const T*)&ry[q];
-            const float* pe = p.pe_t + (size_t)(gr < rend ? gr % p.T : 0) * 256 + col;
             u32x4 out;
 #pragma unroll
             for (int e0 = 0; e0 < FR; e0 += 4) {
                 f32x4 d = f32x4{to_f32(src[e0]), to_f32(src[e0 + 1]), to_f32(src[e0 + 2]), to_f32(src[e0 + 3])};
                 drop_apply4(p.drop, (uint32_t)gr * 256u + (uint32_t)(col + e0), d);
-                const f32x4 pe4 = *(const f32x4*)(pe + e0);
-                dal += (d[0] * pe4[0] + d[1] * pe4[1]) + (d[2] * pe4[2] + d[3] * pe4[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sD[q][e0 + r] += d[r];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d[r] = ((bits >> (e0 + r)) & 1u) ? d[r] : 0.0f;
                 frag_put4<T>(out, e0, d);              // (pairs leave through ONE packed conversion each)
@@ -156,6 +163,14 @@ __global__ void __launch_bounds__(256) prenet_bwd_kernel(const PrenetBwdArgs p) 
     atomicAdd(p.db + n0 + (tid & 127), bsum);
     __syncthreads();
     {
+        float dal = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int id = tid + 256 * q, row = id / CPR, c = id % CPR;
+            const float* pe = p.pe_t + (size_t)((int)(((long long)split * RS + row) % p.T)) * 256 + n0 + c * FR;
+#pragma unroll
+            for (int e = 0; e < FR; ++e) dal += sD[q][e] * pe[e];
+        }
         float* red = (float*)smem;
         const float s = block256_sum(dal, red);
         if (tid == 0) atomicAdd(p.dalpha, s);
