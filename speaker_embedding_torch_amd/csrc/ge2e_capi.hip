@@ -393,7 +393,10 @@ int launch_gemm_ws(ge2e_handle h, hipStream_t st, const GemmArgs& a) {
     int parts = (512 / cg) / 8 * 8;                       // two resident blocks per CU
     if (parts > (ntiles + 7) / 8 * 8) parts = (ntiles + 7) / 8 * 8;
     if (parts < 8) parts = 8;
-    if constexpr (EPI == EPI_PRENET) parts = prenet_ws_parts(a.T);       // 16 parts a multiple of T (the kernel keeps its positional rows in registers)
+    if constexpr (EPI == EPI_PRENET) {
+        parts = prenet_ws_parts(a.T);                     // 16 parts a multiple of T (the kernel keeps its positional rows in registers)
+        if (parts <= 0 || (16LL * parts) % a.T != 0 || cg != 1) return fail(h, GE2E_EUNSUPPORTED, "gemm_ws: no frame-aligned partition for the prenet");
+    }
     const double abytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (reads_r ? 2.0 : 1.0)) +
                           (EPI == EPI_MASKBITS || EPI == EPI_PRENET ? (double)a.M * a.N / 8.0 : 0.0);
     ProfScope ps(h, st, EPI == EPI_LN ? GE2E_K_GEMM_LN : GE2E_K_GEMM, 2.0 * a.M * a.N * (double)a.K, abytes);
@@ -1394,6 +1397,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             const int pd = t / g2;
             const int splits = pd * std::max(1, (256 + pd / 2) / pd);
             a.nsplit = splits;
+            if (((long long)RS * splits) % t != 0) return fail(h, GE2E_EINVAL, "prenet backward: stages are not frame-aligned");
             const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
             ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R * d * c.mel_dim, (double)R * (d + L.KP) * sizeof(T) + (double)R * d / 8 + 4.0 * d * c.mel_dim);
             auto kern = prenet_bwd_kernel<T, PB_NS>;
