@@ -953,7 +953,7 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
         }
     }
     const bool ffn_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && ffn_chain_on();     // read ONCE per forward
-    const bool last_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && samples == 1 && !opt(O_NO_LAST_CHAIN);
+    const bool last_chained = sizeof(T) == 2 && c.ffn == FFN_F && d == 256 && (samples == 1 || (!train && samples <= 16)) && !opt(O_NO_LAST_CHAIN);
     if (train) note_forward(h, ws, ffn_chained);
     // ---- mel batch: one coalesced pass fp32 [N, mel, T] -> T-typed rows [R, KP]; kept for the prenet backward
     if (mel_f16) {
@@ -1021,11 +1021,12 @@ int forward_impl(ge2e_handle h, hipStream_t st, const void* mel, bool mel_f16, i
             if constexpr (sizeof(T) == 2) {
                 LastcArgs a = lastc_args(c, L, ws, P, l, n, t, hin);
                 a.rstd1 = train ? (float*)(ws + L.rstd1[l]) : nullptr; a.rstd2 = train ? (float*)(ws + L.rstd2[l]) : nullptr;
-                a.emb_out = out_emb;
+                a.emb_out = out_emb; a.samples = samples;
                 a.d_sa = make_drop(train, c.tf_dropout, seed, step, site_sa(l)); a.d_fh = make_drop(train, c.tf_dropout, seed, step, site_ffh(l));
                 a.d_ff = make_drop(train, c.tf_dropout, seed, step, site_ff(l));
                 auto kern = lastc_fwd_kernel<T, LASTC_NW>;
-                GE2E_LAUNCH(h, kern, dim3((n + 15) / 16), dim3(LASTC_THREADS), lastc_smem<LASTC_NW>(), st, a);
+                const int per_tile = 16 / samples;          // utterances per 16-row tile
+                GE2E_LAUNCH(h, kern, dim3((n / samples + per_tile - 1) / per_tile), dim3(LASTC_THREADS), lastc_smem<LASTC_NW>(), st, a);
             }
             return 0;
         }

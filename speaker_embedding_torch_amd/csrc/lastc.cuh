@@ -19,7 +19,8 @@
 //   * the projection runs on the bf16 pipe at fp32 accuracy: z and Wq are split into bf16 hi + lo halves, three MFMAs per product
 //     (common.cuh, "fp32x3"; the tail was fp32 arithmetic in every mode and stays at that accuracy: ~1e-5 against 4e-3 of a bf16 rounding).
 // Rounding points are those of the five launches (h1, f, h2 are rounded to the storage type before their next use), so the saved tensors and the
-// d-vector agree with them to the order of the LayerNorm / dot-product sums.  samples == 1 only (a slice mean would cross row tiles).
+// d-vector agree with them to the order of the LayerNorm / dot-product sums.  A tile holds whole utterances: 16 / samples of them (eval mode;
+// training runs with samples == 1).
 //
 // lastc_bwd_kernel is the same chain backwards (see there).
 #pragma once
@@ -30,6 +31,7 @@ namespace ge2e {
 struct LastcArgs {
     int n;                          // compact rows (utterances)
     int abl;                        // (tools/lastc_bench.hip only) ablation bits
+    int samples;                    // forward, eval mode: slices per utterance (rows m samples .. + samples - 1 are averaged after transformer.norm, Modules.py:55); 0 / 1: none
     int drow_mul;                   // dropout counter row = row * drow_mul (the frame-0 row of utterance `row` in the full-height numbering)
     float eps;
     // ---- forward
@@ -193,7 +195,7 @@ __device__ __forceinline__ void lc_put_x3(unsigned char* zh, unsigned char* zl, 
     *(u32x2*)(zh + off) = hi; *(u32x2*)(zl + off) = lo;
 }
 
-// grid = ceil(n / 16) blocks of 64 NW threads
+// grid = ceil((n / samples) / (16 / samples)) blocks of 64 NW threads
 template <typename T, int NW>
 __global__ void __launch_bounds__(64 * NW) lastc_fwd_kernel(const LastcArgs p) {
     static_assert(sizeof(T) == 2, "16-bit storage modes");
@@ -206,9 +208,11 @@ __global__ void __launch_bounds__(64 * NW) lastc_fwd_kernel(const LastcArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
-    const int r0 = blockIdx.x * 16, row = r0 + i;
-    const bool ok = row < p.n;
-    const int rowc = ok ? row : p.n - 1;
+    // a tile holds G = 16 / samples whole utterances (samples = 1: 16 rows; samples = 5: 15 rows, the 16th idles) so that the slice mean stays inside it
+    const int smp = p.samples > 1 ? p.samples : 1, G = 16 / smp, RT = G * smp;
+    const int r0 = blockIdx.x * RT, row = r0 + i;
+    const bool ok = i < RT && row < p.n;
+    const int rowc = row < p.n ? row : p.n - 1;
     const int n0 = wave * 16 * NT;
     const uint32_t drow = (uint32_t)row * (uint32_t)(p.drow_mul > 0 ? p.drow_mul : 1);
 
@@ -349,11 +353,28 @@ __global__ void __launch_bounds__(64 * NW) lastc_fwd_kernel(const LastcArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { xh[r] = (h2v[nt][r] - mean) * rs; z[r] = xh[r] * ga[r] + be[r]; }
             if (p.xhat && ok) *(f32x4*)(p.xhat + (size_t)row * 256 + lc) = xh;
-            if (p.zm && ok) *(f32x4*)(p.zm + (size_t)row * 256 + lc) = z;
-            lc_put_x3(Zh, Zl, lc_off<512>(i, lc), z);
+            if (smp == 1) {
+                if (p.zm && ok) *(f32x4*)(p.zm + (size_t)row * 256 + lc) = z;
+                lc_put_x3(Zh, Zl, lc_off<512>(i, lc), z);
+            } else *(f32x4*)(Fs + 2 * LC_XS + i * 1024 + lc * 4) = z;          // fp32 rows for the slice mean (the hidden tile's upper half)
         }
     }
     __syncthreads();
+    const int m = blockIdx.x * G + i;                      // output row: utterance
+    const bool okm = i < G && m < p.n / smp;
+    if (smp > 1) {                                         // (block-uniform) z' = mean over the utterance's slices; rows past G carry zeros
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int lc = n0 + 16 * nt + 4 * g;
+            f32x4 zp = f32x4{0, 0, 0, 0};
+            if (i < G)
+                for (int q = 0; q < smp; ++q) zp += *(const f32x4*)(Fs + 2 * LC_XS + (i * smp + q) * 1024 + lc * 4);
+            zp *= 1.0f / (float)smp;
+            if (p.zm && okm) *(f32x4*)(p.zm + (size_t)m * 256 + lc) = zp;
+            lc_put_x3(Zh, Zl, lc_off<512>(i, lc), zp);
+        }
+        __syncthreads();
+    }
 
     // ---- e = Wq z + bq;  e /= max(|e|, 1e-12)
     {
@@ -369,14 +390,14 @@ __global__ void __launch_bounds__(64 * NW) lastc_fwd_kernel(const LastcArgs p) {
         ss = cross4_sum(ss);
         lc_exchange2<NW>(Ex1, wave, i, g, ss, unused);
         const float nn = fmaxf(sqrtf(ss), 1e-12f);
-        if (p.nrm && g == 0 && wave == 0 && ok) p.nrm[row] = nn;
-        if (ok) {
+        if (p.nrm && g == 0 && wave == 0 && okm) p.nrm[m] = nn;
+        if (okm) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int lc = n0 + 16 * nt + 4 * g;
                 const f32x4 o = f32x4{e[nt][0] / nn, e[nt][1] / nn, e[nt][2] / nn, e[nt][3] / nn};
-                *(f32x4*)(p.emb + (size_t)row * 256 + lc) = o;
-                if (p.emb_out) *(f32x4*)(p.emb_out + (size_t)row * 256 + lc) = o;
+                *(f32x4*)(p.emb + (size_t)m * 256 + lc) = o;
+                if (p.emb_out) *(f32x4*)(p.emb_out + (size_t)m * 256 + lc) = o;
             }
         }
     }

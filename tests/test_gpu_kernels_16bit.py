@@ -345,3 +345,31 @@ def test_last_layer_chain_matches_its_separate_launches(prec, n, t):
             assert abs(float(ga[k].ravel()[0] - gb[k].ravel()[0])) < 0.05 * nb, k
         else:
             assert tp.rel_l2(gb[k], ga[k]) < (0.05 if prec == "bf16" else 0.01), (k, tp.rel_l2(gb[k], ga[k]))
+
+
+@pytest.mark.parametrize("prec,groups,samples,t", [("bf16", 7, 5, 64), ("fp16", 33, 3, 80), ("bf16", 5, 16, 40)])
+def test_last_layer_chain_multislice_eval(prec, groups, samples, t):
+    """Eval mode with `samples` slices per utterance (Inference.py:157-159; the slice mean of Modules.py:55 sits between transformer.norm and the
+    projection): a row tile of the chain kernel holds 16 // samples whole utterances, so the mean stays inside it.  Against the separate launches
+    (option no_last_chain) on the same input: the d-vectors agree to the roundings of the storage type that the two LayerNorm orders produce."""
+    from speaker_embedding_torch_amd import _lib
+    from speaker_embedding_torch_amd.Modules import GE2E
+    import test_gpu_parity as tp
+    n = groups * samples
+    x = torch.from_numpy(O.formula_mel(23, n, 80, t, logmel=True)).cuda()
+    out = {}
+    for mode in (1, 0):
+        _lib.set_option("no_last_chain", mode)
+        try:
+            m, _, _ = tp.build(GE2E, prec, 0.1)
+            m.eval()
+            with torch.no_grad():
+                out[mode] = m(x, samples).detach().clone()
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_option("no_last_chain", 0)
+    assert out[0].shape == (groups, 256)
+    assert torch.isfinite(out[0]).all()
+    ulp = 2.0 ** -8 if prec == "bf16" else 2.0 ** -11
+    assert tp.rel_l2(out[0].cpu().numpy(), out[1].cpu().numpy()) < 4 * ulp
+    assert (out[0].norm(dim=1) - 1.0).abs().max() < 1e-5
