@@ -3,7 +3,7 @@
     timeout -k 10 600 python tools/soak.py [--steps 1500] [--shapes 150]
 Phase 1: the benchmark shape, `--steps` consecutive Train_Steps (dropout stream advances every step).
 Phase 2: `--shapes` random (speakers, utterances, frames) shapes, bf16, fp32, fp16 and fp32x3 in turn (every 5th with the fused attention sub-layer on), fresh NaN-poisoned workspace,
-one forward + backward + optimizer step each; every gradient must be finite."""
+one forward + backward + optimizer step each; every gradient must be finite; every 3rd shape also embeds a batch in eval mode with 1-6 slices per utterance."""
 import argparse, os, sys, time
 import numpy as np
 import torch
@@ -39,6 +39,11 @@ def main():
         x = bench.synth_mel(S * P, 80, T, 100 + k, dev)
         loss = crit(m(x), P); o.zero_grad(); loss.backward(); o.step()
         ok = np.isfinite(loss.item()) and all(torch.isfinite(p.grad).all().item() for p in m.parameters())
+        if k % 3 == 2:                                               # every 3rd shape also embeds: eval mode, 1-6 slices per utterance
+            smp = int(rng.integers(1, 7)); m.eval()
+            with torch.no_grad():
+                e = m(bench.synth_mel(S * smp, 80, T, 200 + k, dev), smp)
+            ok = ok and e.shape[0] == S and torch.isfinite(e).all().item() and (e.norm(dim=1) - 1.0).abs().max().item() < 1e-3
         if not ok or k % 25 == 24:
             print(f"phase 2 shape {k + 1}: S={S} P={P} T={T} {prec} loss {loss.item():.4f} finite={ok}", flush=True)
         assert ok, (S, P, T, prec)
