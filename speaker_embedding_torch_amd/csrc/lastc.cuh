@@ -12,10 +12,13 @@
 // statistics: the backward and the weight gradients read them) goes to memory:
 //   * NW waves; wave w owns NT = 16 / NW column tiles of every 256-column group: acc[q][nt][r] = C[row i][256 q + n0 + 16 nt + 4 g + r], n0 = 16 NT w;
 //     the weights are the MFMA's first operand, read from global memory (L2: 60 blocks stream the same 1.3 MB) as 16-byte row fragments in rounds
-//     of 16 per wave, the next round in flight under this round's MFMAs and a product's FIRST round issued before the previous product's epilogue
-//     and barrier (what bounds the kernel is how many such rounds follow one another -- each is an L2 round trip for 128 cycles of MFMA --, so
-//     more, narrower waves are faster: LASTC_NW); the activation tile is the second operand, from a swizzled LDS row tile;
-//   * a row's LayerNorm statistics are a lane-quartet reduction + one LDS exchange between the four waves (Chan's formula, as gemm_ws.cuh);
+//     of 16 per wave, the next round in flight under this round's MFMAs (a scheduling barrier keeps the compiler from sinking each load to just
+//     before its use) and a product's FIRST round issued before the previous product's epilogue and barrier; the activation tile is the second
+//     operand, from a swizzled LDS row tile.  The products run at the rate a CU ingests 64-byte row fragments from L2 (~46 GB/s: 10 us per
+//     512 KB weight; 4, 8 or 16 waves alike -- tools/lastc_bench.hip, profiles/r04_ab_log.txt section 6);
+//   * every per-column constant (-> LDS) and every saved row is fetched in ONE prologue round trip: fetched where they are used, each epilogue
+//     was one more dependent L2 round trip, eleven of them half of the first version's time;
+//   * a row's LayerNorm statistics are a lane-quartet reduction + one LDS exchange between the waves (Chan's formula, as gemm_ws.cuh);
 //   * the projection runs on the bf16 pipe at fp32 accuracy: z and Wq are split into bf16 hi + lo halves, three MFMAs per product
 //     (common.cuh, "fp32x3"; the tail was fp32 arithmetic in every mode and stays at that accuracy: ~1e-5 against 4e-3 of a bf16 rounding).
 // Rounding points are those of the five launches (h1, f, h2 are rounded to the storage type before their next use), so the saved tensors and the
