@@ -20,9 +20,6 @@
 #include "attn_last.cuh"
 #include "attn_sub.cuh"
 #include "prenet_bwd.cuh"
-#ifndef PB_NS
-#define PB_NS 3
-#endif
 #include "gemm.cuh"
 #include "gemm_ws.cuh"
 #include "gemm_kl.cuh"
@@ -1401,7 +1398,7 @@ int backward_body(ge2e_handle h, hipStream_t st, SideCtx& sc, const float* mel, 
             if (((long long)RS * splits) % t != 0) return fail(h, GE2E_EINVAL, "prenet backward: stages are not frame-aligned");
             const size_t smem = std::max<size_t>(4 * (size_t)RS * LD, 128 * (128 * 4 + 16));
             ProfScope ps(h, st, GE2E_K_WGRAD, 2.0 * R * d * c.mel_dim, (double)R * (d + L.KP) * sizeof(T) + (double)R * d / 8 + 4.0 * d * c.mel_dim);
-            auto kern = prenet_bwd_kernel<T, PB_NS>;
+            auto kern = prenet_bwd_kernel<T>;
             GE2E_LAUNCH(h, kern, dim3(2 * splits), dim3(256), smem, st, a);
         } else {
         GemmArgs a{};

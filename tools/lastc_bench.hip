@@ -1,6 +1,7 @@
 // The last layer's compact chain kernels (lastc.cuh) alone on the chip, caches flushed between launches (development tool).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I speaker_embedding_torch_amd/csrc tools/lastc_bench.hip -o tools/lastc_bench
-//   tools/lastc_bench [n = 960]
+//   hipcc [-DLASTC_NW=4|8|16] --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I speaker_embedding_torch_amd/csrc tools/lastc_bench.hip -o tools/lastc_bench
+//   tools/lastc_bench [n = 960]      (then: ablation runs, LastcArgs::abl bits 1 / 2 / 4 / 8 = forward without product 1-4, 16 = no hidden store,
+//                                      32 / 64 / 128 / 256 = backward without product 1-4; the last two lines: backward without its column-sum atomics)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
